@@ -1,0 +1,31 @@
+"""Shared pytest configuration: paths, markers, golden fixtures."""
+import json
+import pathlib
+import sys
+
+import pytest
+import torch
+
+REPO = pathlib.Path(__file__).resolve().parent.parent
+for p in (REPO, REPO / 'neuron-descriptions_amd'):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+GOLDEN_DIR = REPO / 'tests' / 'golden'
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers',
+                            'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def goldens():
+    """Tensors produced by the imported reference (tests/golden/make_golden.py)."""
+    return torch.load(GOLDEN_DIR / 'reference_goldens.pt')
+
+
+@pytest.fixture(scope='session')
+def golden_meta():
+    with open(GOLDEN_DIR / 'reference_goldens.json') as f:
+        return json.load(f)
