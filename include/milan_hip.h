@@ -1,0 +1,183 @@
+/* libmilan_hip -- C ABI of the MI355X-native MILAN inference path.
+ *
+ * The reference (evandez/neuron-descriptions) is pure Python and has no FFI
+ * of its own; the seam this library sits behind is the Python class contract
+ * of `src.milan.Decoder`.  Each entry point below is the
+ * native counterpart of one reference method; the Python mirror in
+ * neuron-descriptions_amd/milan_amd/ binds them with ctypes (INTEGRATION.md
+ * shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Every data pointer is a DEVICE pointer owned by the caller (the Python
+ *     side passes torch tensors' data_ptr()).  The library owns only its packed
+ *     weight arena, freed by milan_destroy().
+ *   - All work is enqueued on `stream` (a hipStream_t); no implicit sync except
+ *     where documented (milan_finalize_weights).
+ *   - Return 0 on success; negative = MILAN_ERR_*; positive = hipError_t.
+ *     milan_last_error() returns a thread-local message for the last failure.
+ *   - float = IEEE binary32 everywhere (the reference computes in fp32); token
+ *     ids are int64 like torch.long.
+ *   - One ctx per device; a ctx is not thread-safe.
+ */
+#ifndef MILAN_HIP_H
+#define MILAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MILAN_ABI_VERSION 1
+
+enum {
+  MILAN_OK = 0,
+  MILAN_ERR_ARG = -1,       /* bad argument (-> ValueError in Python)        */
+  MILAN_ERR_SHAPE = -2,     /* shape/dim mismatch (-> ValueError)            */
+  MILAN_ERR_STATE = -3,     /* call order (weights missing / not finalized)  */
+  MILAN_ERR_WORKSPACE = -4, /* workspace too small                           */
+  MILAN_ERR_NO_LM = -5      /* MI / rerank requested without an LM
+                               (src/milan/decoders.py:397-398)               */
+};
+
+enum { MILAN_DTYPE_U8 = 0, MILAN_DTYPE_F32 = 1 };
+
+/* src/milan/decoders.py:217-221 */
+enum { MILAN_GREEDY = 0, MILAN_BEAM = 2, MILAN_RERANK = 3 };
+
+typedef struct milan_ctx milan_ctx;
+typedef void* milan_stream; /* hipStream_t */
+
+/* Model geometry.  Mirrors the constructor arguments of
+ * src/milan/decoders.py:233-244, src/milan/lms.py:20-25 and the encoder
+ * config of src/milan/encoders.py:326-351 (bottleneck ResNets only). */
+typedef struct milan_dims {
+  int32_t trunk_width;      /* 64 for torchvision resnet50/101/152          */
+  int32_t trunk_blocks[4];  /* {3,4,23,3} = resnet101                        */
+  int32_t feature_size;     /* 61 * trunk_width = 3904                       */
+  int32_t hidden_size;      /* 512                                           */
+  int32_t embedding_size;   /* 128                                           */
+  int32_t attention_size;   /* min(hidden, feature) = 512 (decoders.py:50)   */
+  int32_t vocab_size;       /* len(indexer) = |vocab| + 4                    */
+  int32_t start_index;      /* |vocab|     (src/utils/lang.py:242-245)       */
+  int32_t stop_index;       /* |vocab| + 1                                   */
+  int32_t pad_index;        /* |vocab| + 2                                   */
+  int32_t has_lm;           /* 0/1                                           */
+  int32_t lm_hidden_size;   /* 512                                           */
+  int32_t lm_embedding_size;/* 128                                           */
+  int32_t lm_layers;        /* 2                                             */
+} milan_dims;
+
+int milan_abi_version(void);
+const char* milan_last_error(void);
+
+/* Lifetime.  Replaces Decoder.__init__ / Decoder.to(device). */
+int milan_create(milan_ctx** out, int device, const milan_dims* dims);
+void milan_destroy(milan_ctx* ctx);
+
+/* Weight upload.  `name` is the key in the reference's Decoder.state_dict()
+ * (src/utils/serialize.py:188-204), e.g. "lstm.weight_ih",
+ * "attend.key_to_hidden.weight", "lm.lstm.weight_hh_l1",
+ * "encoder.encoder.model.layer3.7.bn2.running_var".  `data` is a device float*
+ * that must stay valid until milan_finalize_weights() returns.  Unknown names
+ * ("...num_batches_tracked", "...fc.weight": computed-and-discarded by the
+ * reference) are accepted and ignored.  Replaces load_state_dict
+ * (src/utils/serialize.py:222-252). */
+int milan_set_weight(milan_ctx* ctx, const char* name, const float* data,
+                     const int64_t* shape, int ndim);
+/* Folds eval-mode BatchNorm into the convolutions, repacks every matrix into
+ * the kernels' layout inside a library-owned arena, then synchronises
+ * `stream` (after which the caller may free the uploaded tensors). */
+int milan_finalize_weights(milan_ctx* ctx, milan_stream stream);
+
+/* Bytes of scratch the calls below need for at most `max_neurons` neurons of
+ * `k` exemplars at image_size x image_size, `beam_size` beams, `length` steps. */
+size_t milan_workspace_bytes(const milan_ctx* ctx, int max_neurons, int k,
+                             int image_size, int beam_size, int length);
+
+/* Decoder.encode / PyramidConvEncoder.forward
+ * (src/milan/decoders.py:525-546, src/milan/encoders.py:286-320).
+ * images: (n_images,3,H,W) NCHW, uint8 (0..255, converted exactly like
+ * src/milannotations/datasets.py:191-197) or float in [0,1];
+ * masks: (n_images,1,H,W) uint8 {0,1} or float, or NULL (= all ones).
+ * features: (n_images, feature_size) float out. */
+int milan_encode(milan_ctx* ctx, const void* images, int image_dtype,
+                 const void* masks, int mask_dtype, int n_images, int height,
+                 int width, float* features, void* workspace,
+                 size_t workspace_bytes, milan_stream stream);
+
+/* Decoder.init_state (src/milan/decoders.py:548-574).
+ * features (n,k,F) -> h,c (n,hidden). */
+int milan_init_state(milan_ctx* ctx, const float* features, int n, int k,
+                     float* h, float* c, void* workspace,
+                     size_t workspace_bytes, milan_stream stream);
+
+/* Decoder.step (src/milan/decoders.py:576-634), eval mode.
+ * features (rows,k,F); tokens (rows) int64; h,c (rows,hidden) in;
+ * h_lm,c_lm (lm_layers,rows,lm_hidden) in/out or NULL (no MI);
+ * predictions (rows,V), attentions (rows,k), h_out,c_out (rows,hidden) out. */
+int milan_step(milan_ctx* ctx, const float* features, int rows, int k,
+               const int64_t* tokens, const float* h, const float* c,
+               float* h_lm, float* c_lm, float temperature, float* predictions,
+               float* attentions, float* h_out, float* c_out, void* workspace,
+               size_t workspace_bytes, milan_stream stream);
+
+/* Decoder.forward on features (src/milan/decoders.py:335-523), eval mode.
+ *   strategy MILAN_GREEDY: tokens (n,length), scores (n); predictions
+ *     (n,length,V) and attentions (n,length,k) optional (may be NULL);
+ *     beam_* must be NULL.  mi = use the LM per step (decoders.py:624-630).
+ *   strategy MILAN_BEAM / MILAN_RERANK: allennlp-2.10 BeamSearch semantics
+ *     (decoders.py:467-484) then best-of-beam / LM rerank (decoders.py:492-512).
+ *     beam_tokens (n,beam,length) int64, beam_scores (n,beam),
+ *     tokens (n,length), scores (n).  The search always runs `length` steps;
+ *     out_len[g] receives T' (the length allennlp would have returned for
+ *     neuron group g, groups of `group_size` consecutive neurons = the
+ *     reference's forward batch), positions >= T' hold stop_index.  Rerank LM
+ *     scores use only the first T' tokens, as the reference does.
+ *     out_len is a DEVICE int32 array of ceil(n/group_size) entries. */
+int milan_decode(milan_ctx* ctx, const float* features, int n, int k,
+                 int strategy, int length, int beam_size, int mi,
+                 float temperature, int group_size, int64_t* tokens,
+                 float* scores, float* predictions, float* attentions,
+                 int64_t* beam_tokens, float* beam_scores, int32_t* out_len,
+                 void* workspace, size_t workspace_bytes, milan_stream stream);
+
+/* LanguageModel.forward(inputs, reduce=True) (src/milan/lms.py:58-101),
+ * including its stop-mask off-by-one.  seqs (rows,L) int64, first column is
+ * the start token; out (rows).  seq_len: optional DEVICE int32 per row giving
+ * the number of valid columns (<= L) or NULL (= L). */
+int milan_lm_score(milan_ctx* ctx, const int64_t* seqs, int rows, int L,
+                   const int32_t* seq_len, float* out, void* workspace,
+                   size_t workspace_bytes, milan_stream stream);
+
+/* The whole hot path for one batch = Decoder.forward(images, masks, ...)
+ * (what Decoder.predict calls per batch, src/milan/decoders.py:857-865):
+ * encode then decode.  images (n,k,3,H,W), masks (n,k,1,H,W); other
+ * arguments as milan_decode.  features_out (n,k,F) optional. */
+int milan_describe(milan_ctx* ctx, const void* images, int image_dtype,
+                   const void* masks, int mask_dtype, int n, int k, int height,
+                   int width, int strategy, int length, int beam_size, int mi,
+                   float temperature, int group_size, float* features_out,
+                   int64_t* tokens, float* scores, float* predictions,
+                   float* attentions, int64_t* beam_tokens, float* beam_scores,
+                   int32_t* out_len, void* workspace, size_t workspace_bytes,
+                   milan_stream stream);
+
+/* Building block exposed for kernel-level parity tests: one NHWC fp32
+ * convolution through the same implicit-GEMM MFMA kernel the trunk uses
+ * (counterpart of torch.nn.functional.conv2d as torchvision's ResNet calls it).
+ * x (n,h,w,cin) NHWC with cin % 4 == 0; weight (cout,cin,kh,kw) OIHW as in the
+ * reference state dict; bias (cout) or NULL; residual (n,ho,wo,cout) or NULL
+ * (residual implies relu(conv + bias + residual)); y (n,ho,wo,cout).
+ * Allocates temporaries and synchronises: not for the hot path. */
+int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
+                      const float* weight_oihw, const float* bias, int cout,
+                      int kh, int kw, int stride, int pad, int relu,
+                      const float* residual, float* y, milan_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MILAN_HIP_H */

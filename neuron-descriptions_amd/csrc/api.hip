@@ -1,0 +1,262 @@
+// extern "C" surface of libmilan_hip (see include/milan_hip.h).
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace milan {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int dev_alloc(milan_ctx* c, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  MILAN_CHECK_HIP(hipMalloc(p, (bytes + 255) & ~size_t(255)));
+  c->owned.push_back(*p);
+  return 0;
+}
+
+}  // namespace milan
+
+using namespace milan;
+
+extern "C" {
+
+int milan_abi_version(void) { return MILAN_ABI_VERSION; }
+
+const char* milan_last_error(void) { return g_err; }
+
+int milan_create(milan_ctx** out, int device, const milan_dims* dims) {
+  MILAN_REQUIRE(out && dims, MILAN_ERR_ARG, "milan_create: null argument");
+  const milan_dims& d = *dims;
+  MILAN_REQUIRE(d.trunk_width > 0 && d.trunk_width % 4 == 0, MILAN_ERR_SHAPE,
+                "trunk_width %d must be a positive multiple of 4", d.trunk_width);
+  MILAN_REQUIRE(d.feature_size == 61 * d.trunk_width, MILAN_ERR_SHAPE,
+                "feature_size %d != 61 * trunk_width (pyramid of conv1 + 4 "
+                "bottleneck stages)", d.feature_size);
+  for (int i = 0; i < 4; ++i)
+    MILAN_REQUIRE(d.trunk_blocks[i] > 0, MILAN_ERR_SHAPE, "bad trunk_blocks");
+  MILAN_REQUIRE(d.hidden_size > 0 && d.hidden_size % 4 == 0 &&
+                    d.embedding_size > 0 && d.embedding_size % 4 == 0 &&
+                    d.attention_size > 0 && d.attention_size % 4 == 0,
+                MILAN_ERR_SHAPE,
+                "hidden/embedding/attention sizes must be positive multiples of 4");
+  MILAN_REQUIRE(d.vocab_size > 4 && d.start_index >= 0 &&
+                    d.start_index < d.vocab_size && d.stop_index >= 0 &&
+                    d.stop_index < d.vocab_size,
+                MILAN_ERR_SHAPE, "bad vocab_size / special indices");
+  if (d.has_lm)
+    MILAN_REQUIRE(d.lm_layers >= 1 && d.lm_hidden_size % 4 == 0 &&
+                      d.lm_embedding_size % 4 == 0 && d.lm_hidden_size > 0 &&
+                      d.lm_embedding_size > 0,
+                  MILAN_ERR_SHAPE, "bad LM dimensions");
+  MILAN_CHECK_HIP(hipSetDevice(device));
+  milan_ctx* c = new milan_ctx();
+  c->device = device;
+  c->d = d;
+  int r = dev_alloc(c, (void**)&c->zero, 256);
+  if (r == 0) {
+    hipError_t e = hipMemset(c->zero, 0, 256);
+    if (e != hipSuccess) r = (int)e;
+  }
+  if (r != 0) { milan_destroy(c); return r; }
+  *out = c;
+  return 0;
+}
+
+void milan_destroy(milan_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (void* p : c->owned) (void)hipFree(p);
+  delete c;
+}
+
+int milan_set_weight(milan_ctx* c, const char* name, const float* data,
+                     const int64_t* shape, int ndim) {
+  MILAN_REQUIRE(c && name && data && (shape || ndim == 0) && ndim >= 0 && ndim <= 8,
+                MILAN_ERR_ARG, "milan_set_weight: bad argument");
+  MILAN_REQUIRE(!c->finalized, MILAN_ERR_STATE,
+                "milan_set_weight after milan_finalize_weights");
+  Tensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.dev = data;
+  c->raw[name] = t;
+  return 0;
+}
+
+int milan_finalize_weights(milan_ctx* c, milan_stream stream) {
+  MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
+  MILAN_REQUIRE(!c->finalized, MILAN_ERR_STATE, "weights already finalized");
+  hipStream_t s = (hipStream_t)stream;
+  MILAN_CHECK_HIP(hipSetDevice(c->device));
+  MILAN_TRY(encoder_finalize(c, s));
+  MILAN_TRY(decoder_finalize(c, s));
+  MILAN_REQUIRE(c->stem.w || c->lstm_ih.w, MILAN_ERR_STATE,
+                "no encoder and no decoder weights were uploaded");
+  MILAN_CHECK_HIP(hipStreamSynchronize(s));
+  c->raw.clear();
+  c->finalized = true;
+  return 0;
+}
+
+size_t milan_workspace_bytes(const milan_ctx* c, int max_neurons, int k,
+                             int image_size, int beam_size, int length) {
+  if (!c || max_neurons <= 0 || k <= 0) return 0;
+  size_t enc = 0, dec = 0;
+  if (image_size > 0)
+    enc = encoder_workspace(c, max_neurons * k, image_size, image_size);
+  dec = decoder_workspace(c, max_neurons, k, beam_size < 1 ? 1 : beam_size,
+                          length < 1 ? 1 : length);
+  // + an internal features buffer for milan_describe + slack for alignment
+  return (enc > dec ? enc : dec) +
+         (size_t)max_neurons * k * c->d.feature_size * sizeof(float) + (1 << 16);
+}
+
+static int make_arena(void* ws, size_t bytes, Arena* a) {
+  MILAN_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, MILAN_ERR_WORKSPACE,
+                "workspace must be a non-null 256-byte aligned device pointer");
+  a->base = (char*)ws;
+  a->size = bytes;
+  a->off = 0;
+  return 0;
+}
+
+int milan_encode(milan_ctx* c, const void* images, int image_dtype,
+                 const void* masks, int mask_dtype, int n_images, int height,
+                 int width, float* features, void* workspace,
+                 size_t workspace_bytes, milan_stream stream) {
+  MILAN_REQUIRE(c && images && features, MILAN_ERR_ARG, "milan_encode: null argument");
+  MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
+  MILAN_REQUIRE((image_dtype == MILAN_DTYPE_U8 || image_dtype == MILAN_DTYPE_F32) &&
+                    (mask_dtype == MILAN_DTYPE_U8 || mask_dtype == MILAN_DTYPE_F32),
+                MILAN_ERR_ARG, "bad dtype");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  return encoder_run(c, images, image_dtype, masks, mask_dtype, n_images, height,
+                     width, features, a, (hipStream_t)stream);
+}
+
+int milan_init_state(milan_ctx* c, const float* features, int n, int k, float* h,
+                     float* cc, void* workspace, size_t workspace_bytes,
+                     milan_stream stream) {
+  MILAN_REQUIRE(c && features && h && cc, MILAN_ERR_ARG, "null argument");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  return decoder_init_state(c, features, n, k, h, cc, a, (hipStream_t)stream);
+}
+
+int milan_step(milan_ctx* c, const float* features, int rows, int k,
+               const int64_t* tokens, const float* h, const float* cc,
+               float* h_lm, float* c_lm, float temperature, float* predictions,
+               float* attentions, float* h_out, float* c_out, void* workspace,
+               size_t workspace_bytes, milan_stream stream) {
+  MILAN_REQUIRE(c && features && tokens && h && cc && predictions && h_out && c_out,
+                MILAN_ERR_ARG, "milan_step: null argument");
+  MILAN_REQUIRE(rows > 0, MILAN_ERR_SHAPE, "milan_step: empty batch");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  return decoder_step(c, features, rows, k, tokens, h, cc, h_lm, c_lm,
+                      temperature, predictions, attentions, h_out, c_out, a,
+                      (hipStream_t)stream);
+}
+
+int milan_decode(milan_ctx* c, const float* features, int n, int k, int strategy,
+                 int length, int beam_size, int mi, float temperature,
+                 int group_size, int64_t* tokens, float* scores,
+                 float* predictions, float* attentions, int64_t* beam_tokens,
+                 float* beam_scores, int32_t* out_len, void* workspace,
+                 size_t workspace_bytes, milan_stream stream) {
+  MILAN_REQUIRE(c && features, MILAN_ERR_ARG, "milan_decode: null argument");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  return decoder_decode(c, features, n, k, strategy, length, beam_size, mi,
+                        temperature, group_size, tokens, scores, predictions,
+                        attentions, beam_tokens, beam_scores, out_len, a,
+                        (hipStream_t)stream);
+}
+
+int milan_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
+                   const int32_t* seq_len, float* out, void* workspace,
+                   size_t workspace_bytes, milan_stream stream) {
+  MILAN_REQUIRE(c && seqs && out, MILAN_ERR_ARG, "milan_lm_score: null argument");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  return decoder_lm_score(c, seqs, rows, L, seq_len, out, a, (hipStream_t)stream);
+}
+
+int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
+                      const float* weight_oihw, const float* bias, int cout,
+                      int kh, int kw, int stride, int pad, int relu,
+                      const float* residual, float* y, milan_stream stream) {
+  MILAN_REQUIRE(x && weight_oihw && y, MILAN_ERR_ARG, "conv2d: null argument");
+  MILAN_REQUIRE(cin % 4 == 0 && n > 0 && cout > 0, MILAN_ERR_SHAPE,
+                "conv2d: cin must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const int K = kh * kw * cin, Kp = (K + 31) / 32 * 32;
+  float *wp = nullptr, *zero = nullptr;
+  MILAN_CHECK_HIP(hipMalloc((void**)&wp, sizeof(float) * (size_t)cout * Kp));
+  MILAN_CHECK_HIP(hipMalloc((void**)&zero, 256));
+  MILAN_CHECK_HIP(hipMemsetAsync(zero, 0, 256, s));
+  int r = pack_conv_plain(weight_oihw, cout, cin, kh, kw, wp, s);
+  if (r == 0) {
+    GemmArgs g{};
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    g.A = x; g.W = wp; g.bias = bias; g.aux = residual; g.C = y;
+    g.M = n * ho * wo; g.N = cout; g.K = K; g.Kp = Kp; g.ldc = cout; g.ldaux = cout;
+    g.H = h; g.Wd = w; g.Cin = cin; g.Ho = ho; g.Wo = wo; g.KH = kh; g.KW = kw;
+    g.stride = stride; g.pad = pad; g.a_pix_stride = cin;
+    g.a_img_stride = (long)h * w * cin;
+    g.epilogue = residual ? EPI_BIAS_RES_RELU : (relu ? EPI_BIAS_RELU : EPI_BIAS);
+    g.zero = zero;
+    r = launch_gemm(g, s);
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(wp);
+  (void)hipFree(zero);
+  if (r == 0 && e != hipSuccess) {
+    set_error("conv2d: %s", hipGetErrorString(e));
+    r = (int)e;
+  }
+  return r;
+}
+
+int milan_describe(milan_ctx* c, const void* images, int image_dtype,
+                   const void* masks, int mask_dtype, int n, int k, int height,
+                   int width, int strategy, int length, int beam_size, int mi,
+                   float temperature, int group_size, float* features_out,
+                   int64_t* tokens, float* scores, float* predictions,
+                   float* attentions, int64_t* beam_tokens, float* beam_scores,
+                   int32_t* out_len, void* workspace, size_t workspace_bytes,
+                   milan_stream stream) {
+  MILAN_REQUIRE(c && images, MILAN_ERR_ARG, "milan_describe: null argument");
+  MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
+  MILAN_REQUIRE(n > 0 && k > 0, MILAN_ERR_SHAPE, "milan_describe: empty batch");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  const size_t fcount = (size_t)n * k * c->d.feature_size;
+  float* feats = features_out;
+  if (!feats) {
+    feats = a.get<float>(fcount);
+    MILAN_REQUIRE(feats, MILAN_ERR_WORKSPACE, "describe: workspace too small");
+  }
+  // encoder and decoder scratch reuse the same region one after the other
+  Arena enc;
+  enc.base = a.base + a.off; enc.size = a.size - a.off; enc.off = 0;
+  MILAN_TRY(encoder_run(c, images, image_dtype, masks, mask_dtype, n * k, height,
+                        width, feats, enc, (hipStream_t)stream));
+  Arena dec = enc;
+  dec.off = 0;
+  return decoder_decode(c, feats, n, k, strategy, length, beam_size, mi,
+                        temperature, group_size, tokens, scores, predictions,
+                        attentions, beam_tokens, beam_scores, out_len, dec,
+                        (hipStream_t)stream);
+}
+
+}  // extern "C"

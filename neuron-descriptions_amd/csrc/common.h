@@ -1,0 +1,182 @@
+// Shared host-side declarations for libmilan_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/milan_hip.h"
+
+namespace milan {
+
+// ---- error plumbing (no C++ exceptions cross the C ABI) --------------------
+void set_error(const char* fmt, ...);
+#define MILAN_CHECK_HIP(expr)                                              \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) {                                                \
+      milan::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,       \
+                       hipGetErrorString(_e));                             \
+      return (int)_e;                                                      \
+    }                                                                      \
+  } while (0)
+#define MILAN_REQUIRE(cond, code, ...)                                     \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      milan::set_error(__VA_ARGS__);                                       \
+      return (code);                                                       \
+    }                                                                      \
+  } while (0)
+#define MILAN_TRY(expr)                                                    \
+  do {                                                                     \
+    int _r = (expr);                                                       \
+    if (_r != 0) return _r;                                                \
+  } while (0)
+
+// ---- implicit-GEMM (conv / linear) -----------------------------------------
+enum Epilogue : int {
+  EPI_BIAS = 0,           // C = acc + bias
+  EPI_BIAS_RELU = 1,      // C = relu(acc + bias)
+  EPI_BIAS_RES_RELU = 2,  // C = relu(acc + bias + aux)
+  EPI_BIAS_TANH = 3,      // C = tanh(acc + bias)
+  EPI_BIAS_SIGMUL = 4,    // C = sigmoid(acc + bias) * aux
+  EPI_BIAS_ADD = 5,       // C = acc + bias + aux
+};
+
+// C[M][N] (row stride ldc) = epi( A (*) W^T + bias ), fp32 MFMA, exact f32.
+// A is an NHWC activation tensor addressed as an implicit im2col matrix:
+//   row m = (img, ho, wo), column kk = (kh, kw, cin) with cin fastest.
+// A plain linear layer is the 1x1 case with H = W = 1 and `a_pix_stride`
+// the row stride of the (possibly strided) input matrix.
+struct GemmArgs {
+  const float* A;
+  const float* W;     // packed [N][Kp], Kp = round_up(K, 32), zero padded
+  const float* bias;  // [N] or nullptr
+  const float* aux;   // residual / multiplicand, row stride ldaux, or nullptr
+  float* C;
+  int M, N, K, Kp;
+  int ldc, ldaux;
+  // conv geometry
+  int H, Wd, Cin, Ho, Wo, KH, KW, stride, pad;
+  long a_pix_stride;  // floats between consecutive input pixels (>= Cin)
+  long a_img_stride;  // floats between consecutive images
+  int epilogue;
+  const float* zero;  // >= 64 B of zeros (device)
+};
+
+int launch_gemm(const GemmArgs& g, hipStream_t s);
+
+inline GemmArgs linear_args(const float* A, long lda, const float* W,
+                            const float* bias, float* C, int ldc, int M, int N,
+                            int K, int epi, const float* zero,
+                            const float* aux = nullptr, int ldaux = 0) {
+  GemmArgs g{};
+  g.A = A; g.W = W; g.bias = bias; g.aux = aux; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.Kp = (K + 31) / 32 * 32;
+  g.ldc = ldc; g.ldaux = ldaux;
+  g.H = 1; g.Wd = 1; g.Cin = K; g.Ho = 1; g.Wo = 1; g.KH = 1; g.KW = 1;
+  g.stride = 1; g.pad = 0;
+  g.a_pix_stride = lda; g.a_img_stride = lda;
+  g.epilogue = epi; g.zero = zero;
+  return g;
+}
+
+// ---- packed weights ----------------------------------------------------------
+struct ConvW {
+  float* w = nullptr;     // [Cout][Kp]
+  float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
+  int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;
+};
+struct Bottleneck {
+  ConvW c1, c2, c3, down;
+  bool has_down = false;
+};
+struct LinearW {
+  float* w = nullptr;  // [N][Kp]
+  float* b = nullptr;
+  int n = 0, k = 0, kp = 0;
+};
+
+struct Tensor {
+  std::vector<int64_t> shape;
+  const float* dev = nullptr;  // caller-owned device pointer (until finalize)
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto d : shape) n *= d;
+    return n;
+  }
+};
+
+// bump allocator over a caller-provided workspace
+struct Arena {
+  char* base = nullptr;
+  size_t size = 0, off = 0;
+  bool dry = false;  // dry run: only count
+  template <typename T>
+  T* get(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    size_t o = off;
+    off += bytes;
+    if (dry) return nullptr;
+    if (off > size) return nullptr;
+    return reinterpret_cast<T*>(base + o);
+  }
+};
+
+}  // namespace milan
+
+struct milan_ctx {
+  int device = 0;
+  milan_dims d{};
+  bool finalized = false;
+  std::map<std::string, milan::Tensor> raw;  // named reference tensors
+  // weight arena (library-owned, freed in milan_destroy)
+  std::vector<void*> owned;
+  float* zero = nullptr;
+  // encoder
+  milan::ConvW stem;
+  float *bn1_scale = nullptr, *bn1_shift = nullptr;
+  std::vector<milan::Bottleneck> blocks[4];
+  float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  // decoder
+  milan::LinearW init_h, init_c, q2h, k2h, gate, lstm_ih, lstm_hh, out;
+  float *att_w = nullptr, *att_b = nullptr;  // attend.output.0: [A], [1]
+  float* embedding = nullptr;                // [V][E]
+  // language model
+  std::vector<milan::LinearW> lm_ih, lm_hh;  // per layer
+  milan::LinearW lm_out;
+  float* lm_embedding = nullptr;
+};
+
+namespace milan {
+int dev_alloc(milan_ctx* c, void** p, size_t bytes);
+// encoder.hip
+int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
+                    float* wp, hipStream_t s);
+int encoder_finalize(milan_ctx* c, hipStream_t s);
+size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W);
+int encoder_run(milan_ctx* c, const void* images, int image_dtype,
+                const void* masks, int mask_dtype, int n_images, int H, int W,
+                float* features, Arena& ws, hipStream_t s);
+// decoder.hip
+int decoder_finalize(milan_ctx* c, hipStream_t s);
+size_t decoder_workspace(const milan_ctx* c, int n, int k, int beam, int length);
+int decoder_init_state(milan_ctx* c, const float* features, int n, int k,
+                       float* h, float* cc, Arena& ws, hipStream_t s);
+int decoder_step(milan_ctx* c, const float* features, int rows, int k,
+                 const int64_t* tokens, const float* h, const float* cc,
+                 float* h_lm, float* c_lm, float temperature,
+                 float* predictions, float* attentions, float* h_out,
+                 float* c_out, Arena& ws, hipStream_t s);
+int decoder_decode(milan_ctx* c, const float* features, int n, int k,
+                   int strategy, int length, int beam, int mi,
+                   float temperature, int group_size, int64_t* tokens,
+                   float* scores, float* predictions, float* attentions,
+                   int64_t* beam_tokens, float* beam_scores, int32_t* out_len,
+                   Arena& ws, hipStream_t s);
+int decoder_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
+                     const int32_t* seq_len, float* out, Arena& ws,
+                     hipStream_t s);
+}  // namespace milan

@@ -1,0 +1,959 @@
+// Attention-LSTM caption decoder, beam search and LM (PMI) rerank.
+//
+// Mirrors src/milan/decoders.py (init_state :548-574, Attention.forward
+// :57-73, step :576-634, greedy loop :431-463, allennlp BeamSearch call
+// :467-484, rerank epilogue :495-512) and src/milan/lms.py:58-101.
+//
+// Work split: every dense product goes through the fp32-MFMA GEMM of
+// gemm.hip; what is here is the glue that is HBM/latency bound: the k-way
+// additive attention (wave reductions), the context sum, LSTM cell
+// pointwise, per-row log-softmax + top-k, the beam merge, index-only beam
+// reordering (the (rows,k,F) features never move: a row reads its neuron's
+// features through row / rows_per_neuron) and the LM gather/mask sum.
+//
+// The key projection W_k f_k (decoders.py:71) is hoisted: it depends on the
+// neuron only, so it is computed once per neuron instead of once per step per
+// beam row (68% of the reference decoder's FLOPs).
+#include "common.h"
+#include <limits>
+
+namespace milan {
+
+static constexpr float kFloatMin = -3.402823466e+38f;  // torch.finfo(f32).min
+
+static const Tensor* find(milan_ctx* c, const std::string& name) {
+  auto it = c->raw.find(name);
+  return it == c->raw.end() ? nullptr : &it->second;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+__global__ void pack_rows_kernel(const float* __restrict__ src, int n, int k,
+                                 int kp, float* __restrict__ dst) {
+  const long total = (long)n * kp;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int r = idx / kp, col = idx - (long)r * kp;
+    dst[idx] = col < k ? src[(long)r * k + col] : 0.f;
+  }
+}
+
+__global__ void add_vec_kernel(const float* a, const float* b, int n,
+                               float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + (b ? b[i] : 0.f);
+}
+
+static int copy_vec(milan_ctx* c, const Tensor* t, float** out, hipStream_t s) {
+  MILAN_TRY(dev_alloc(c, (void**)out, sizeof(float) * t->numel()));
+  MILAN_CHECK_HIP(hipMemcpyAsync(*out, t->dev, sizeof(float) * t->numel(),
+                                 hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+static int pack_linear(milan_ctx* c, const std::string& wname,
+                       const std::string& bname, int n, int k, LinearW* out,
+                       hipStream_t s) {
+  const Tensor* w = find(c, wname);
+  MILAN_REQUIRE(w, MILAN_ERR_STATE, "missing weight %s", wname.c_str());
+  MILAN_REQUIRE(w->shape.size() == 2 && w->shape[0] == n && w->shape[1] == k,
+                MILAN_ERR_SHAPE, "%s: expected (%d,%d), got (%lld,%lld)",
+                wname.c_str(), n, k, (long long)w->shape[0],
+                (long long)(w->shape.size() > 1 ? w->shape[1] : -1));
+  MILAN_REQUIRE(k % 4 == 0, MILAN_ERR_SHAPE,
+                "%s: inner dimension %d must be a multiple of 4", wname.c_str(),
+                k);
+  out->n = n; out->k = k; out->kp = (k + 31) / 32 * 32;
+  MILAN_TRY(dev_alloc(c, (void**)&out->w, sizeof(float) * (size_t)n * out->kp));
+  const long total = (long)n * out->kp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, s, w->dev, n,
+                     k, out->kp, out->w);
+  MILAN_CHECK_HIP(hipGetLastError());
+  if (!bname.empty()) {
+    const Tensor* b = find(c, bname);
+    MILAN_REQUIRE(b && b->numel() == n, MILAN_ERR_STATE, "missing/bad bias %s",
+                  bname.c_str());
+    MILAN_TRY(copy_vec(c, b, &out->b, s));
+  }
+  return 0;
+}
+
+int decoder_finalize(milan_ctx* c, hipStream_t s) {
+  if (!find(c, "lstm.weight_ih")) return 0;  // encoder-only context
+  const milan_dims& d = c->d;
+  const int F = d.feature_size, H = d.hidden_size, E = d.embedding_size,
+            A = d.attention_size, V = d.vocab_size;
+  MILAN_TRY(pack_linear(c, "init_h.0.weight", "init_h.0.bias", H, F, &c->init_h, s));
+  MILAN_TRY(pack_linear(c, "init_c.0.weight", "init_c.0.bias", H, F, &c->init_c, s));
+  MILAN_TRY(pack_linear(c, "attend.query_to_hidden.weight",
+                        "attend.query_to_hidden.bias", A, H, &c->q2h, s));
+  MILAN_TRY(pack_linear(c, "attend.key_to_hidden.weight",
+                        "attend.key_to_hidden.bias", A, F, &c->k2h, s));
+  MILAN_TRY(pack_linear(c, "feature_gate.0.weight", "feature_gate.0.bias", F, H,
+                        &c->gate, s));
+  MILAN_TRY(pack_linear(c, "lstm.weight_ih", "lstm.bias_ih", 4 * H, E + F,
+                        &c->lstm_ih, s));
+  MILAN_TRY(pack_linear(c, "lstm.weight_hh", "lstm.bias_hh", 4 * H, H,
+                        &c->lstm_hh, s));
+  MILAN_TRY(pack_linear(c, "output.1.weight", "output.1.bias", V, H, &c->out, s));
+  {
+    const Tensor *w = find(c, "attend.output.0.weight"),
+                 *b = find(c, "attend.output.0.bias"),
+                 *e = find(c, "embedding.weight");
+    MILAN_REQUIRE(w && b && e, MILAN_ERR_STATE,
+                  "missing attend.output.0.* or embedding.weight");
+    MILAN_REQUIRE(w->numel() == A && e->numel() == (int64_t)V * E,
+                  MILAN_ERR_SHAPE, "attend.output / embedding shape mismatch");
+    MILAN_TRY(copy_vec(c, w, &c->att_w, s));
+    MILAN_TRY(copy_vec(c, b, &c->att_b, s));
+    MILAN_TRY(copy_vec(c, e, &c->embedding, s));
+  }
+  if (d.has_lm) {
+    const int Hl = d.lm_hidden_size, El = d.lm_embedding_size;
+    c->lm_ih.resize(d.lm_layers);
+    c->lm_hh.resize(d.lm_layers);
+    for (int l = 0; l < d.lm_layers; ++l) {
+      const std::string sfx = "_l" + std::to_string(l);
+      MILAN_TRY(pack_linear(c, "lm.lstm.weight_ih" + sfx, "lm.lstm.bias_ih" + sfx,
+                            4 * Hl, l == 0 ? El : Hl, &c->lm_ih[l], s));
+      MILAN_TRY(pack_linear(c, "lm.lstm.weight_hh" + sfx, "lm.lstm.bias_hh" + sfx,
+                            4 * Hl, Hl, &c->lm_hh[l], s));
+    }
+    MILAN_TRY(pack_linear(c, "lm.output.0.weight", "lm.output.0.bias", V, Hl,
+                          &c->lm_out, s));
+    const Tensor* e = find(c, "lm.embedding.weight");
+    MILAN_REQUIRE(e && e->numel() == (int64_t)V * El, MILAN_ERR_STATE,
+                  "missing/bad lm.embedding.weight");
+    MILAN_TRY(copy_vec(c, e, &c->lm_embedding, s));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+// pooled[n][f] = mean_k features[n][k][f]      (decoders.py:564)
+__global__ void mean_k_kernel(const float* __restrict__ feat, int n, int k,
+                              int F, float* __restrict__ pooled) {
+  const long total = (long)n * F;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long i = idx / F;
+    const int f = idx - i * F;
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s += feat[(i * k + j) * F + f];
+    pooled[idx] = s / (float)k;
+  }
+}
+
+// att[r][:] = softmax_k( w . tanh(q[r] + keys[neuron][k]) + b )
+// (decoders.py:70-73).  One wave per row; neuron = r / rpn.
+__global__ __launch_bounds__(256) void attend_kernel(
+    const float* __restrict__ q, const float* __restrict__ keys,
+    const float* __restrict__ w, const float* __restrict__ b, int rows, int rpn,
+    int k, int A, float* __restrict__ att) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* qr = q + (long)r * A;
+  const float* kr = keys + (long)(r / rpn) * k * A;
+  float mine = 0.f;  // lane j keeps score j
+  float mx = -INFINITY;
+  for (int j = 0; j < k; ++j) {
+    float s = 0.f;
+    for (int a = lane; a < A; a += 64) s += w[a] * tanhf(qr[a] + kr[(long)j * A + a]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s += b[0];
+    if (lane == (j & 63)) mine = s;  // k <= 64 enforced by the host
+    mx = fmaxf(mx, s);
+  }
+  float e = lane < k ? expf(mine - mx) : 0.f;
+  float sum = e;
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane < k) att[(long)r * k + lane] = e / sum;
+}
+
+// ctx[r][f] = sum_k att[r][k] * features[neuron][k][f]   (decoders.py:613)
+__global__ __launch_bounds__(256) void context_kernel(
+    const float* __restrict__ att, const float* __restrict__ feat, int rpn,
+    int k, int F, float* __restrict__ ctx) {
+  __shared__ float a[64];
+  const int r = blockIdx.x;
+  if (threadIdx.x < k) a[threadIdx.x] = att[(long)r * k + threadIdx.x];
+  __syncthreads();
+  const float4* f4 = reinterpret_cast<const float4*>(feat + (long)(r / rpn) * k * F);
+  const int F4 = F >> 2;
+  for (int f = blockIdx.y * 256 + threadIdx.x; f < F4; f += gridDim.y * 256) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < k; ++j) {
+      const float4 v = f4[(long)j * F4 + f];
+      const float aj = a[j];
+      s.x += aj * v.x; s.y += aj * v.y; s.z += aj * v.z; s.w += aj * v.w;
+    }
+    reinterpret_cast<float4*>(ctx + (long)r * F)[f] = s;
+  }
+}
+
+// dst[r][0:E] = table[tok[r]]
+__global__ void embed_kernel(const float* __restrict__ table,
+                             const int64_t* __restrict__ tok, int rows, int E,
+                             float* __restrict__ dst, int ldd) {
+  const long total = (long)rows * E;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / E;
+    const int e = idx - r * E;
+    dst[r * ldd + e] = table[tok[r] * E + e];
+  }
+}
+
+// torch LSTM cell pointwise, gate order i,f,g,o.
+__global__ void lstm_pointwise_kernel(const float* __restrict__ gates,
+                                      const float* __restrict__ c_in, int rows,
+                                      int H, float* __restrict__ h_out,
+                                      float* __restrict__ c_out) {
+  const long total = (long)rows * H;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / H;
+    const int j = idx - r * H;
+    const float* g = gates + r * 4 * H;
+    const float gi = 1.f / (1.f + expf(-g[j]));
+    const float gf = 1.f / (1.f + expf(-g[H + j]));
+    const float gg = tanhf(g[2 * H + j]);
+    const float go = 1.f / (1.f + expf(-g[3 * H + j]));
+    const float c2 = gf * c_in[idx] + gi * gg;
+    c_out[idx] = c2;
+    h_out[idx] = go * tanhf(c2);
+  }
+}
+
+// ---- block helpers ----------------------------------------------------------
+__device__ inline float block_max(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ inline float block_sum(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Select the k largest of vals[0..n) (LDS, destroyed); ties -> lowest index.
+// 256 threads.  Thread 0 writes out_v/out_i.
+__device__ inline void block_topk(float* vals, int n, int k, float* out_v,
+                                  int* out_i, float* red_v, int* red_i) {
+  const int tid = threadIdx.x;
+  float bv; int bi;
+  auto rescan = [&]() {
+    bv = -INFINITY; bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+      const float v = vals[i];
+      if (v > bv) { bv = v; bi = i; }
+    }
+  };
+  rescan();
+  for (int j = 0; j < k; ++j) {
+    float v = bv; int i = bi;
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o);
+      const int oi = __shfl_xor(i, o);
+      if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = v; red_i[tid >> 6] = i; }
+    __syncthreads();
+    float wv = red_v[0]; int wi = red_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float ov = red_v[w]; const int oi = red_i[w];
+      if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+    }
+    if (tid == 0) { out_v[j] = wv; out_i[j] = wi; }
+    if (wi != 0x7fffffff && (wi & 255) == tid) {
+      vals[wi] = -INFINITY;
+      rescan();
+    }
+    __syncthreads();
+  }
+}
+
+// Per row: pred = log_softmax(logits) [- lambda * log_softmax(lm_logits)]
+// (decoders.py:621,624-630); optionally store pred; then the top-k of pred
+// (k = beam for allennlp's per-node topk, k = 1 for greedy argmax).  Rows whose
+// last token is <stop> get allennlp's forced distribution instead (0 at stop,
+// finfo.min elsewhere).  One workgroup per row, the row lives in LDS.
+__global__ __launch_bounds__(256) void row_select_kernel(
+    const float* __restrict__ logits, const float* __restrict__ lm_logits,
+    float lambda, int V, int k, const int64_t* __restrict__ last_tok, int stop,
+    float* __restrict__ cand_v, int* __restrict__ cand_i,
+    float* __restrict__ pred_out, long pred_stride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* pred = sm;            // [V]
+  float* red = sm + V;         // [4]
+  int* redi = (int*)(red + 4); // [4]
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long)r * V;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 256) { const float v = x[i]; pred[i] = v; mx = fmaxf(mx, v); }
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int i = tid; i < V; i += 256) s += expf(pred[i] - mx);
+  s = block_sum(s, red);
+  const float ls = logf(s);
+  if (lm_logits) {
+    const float* y = lm_logits + (long)r * V;
+    float my = -INFINITY;
+    for (int i = tid; i < V; i += 256) my = fmaxf(my, y[i]);
+    my = block_max(my, red);
+    float sy = 0.f;
+    for (int i = tid; i < V; i += 256) sy += expf(y[i] - my);
+    sy = block_sum(sy, red);
+    const float lsy = logf(sy);
+    for (int i = tid; i < V; i += 256)
+      pred[i] = ((pred[i] - mx) - ls) - lambda * ((y[i] - my) - lsy);
+  } else {
+    for (int i = tid; i < V; i += 256) pred[i] = (pred[i] - mx) - ls;
+  }
+  if (pred_out) {
+    float* po = pred_out + (long)r * pred_stride;
+    for (int i = tid; i < V; i += 256) po[i] = pred[i];
+  }
+  if (k <= 0) return;
+  __syncthreads();
+  if (last_tok && last_tok[r] == stop) {
+    for (int j = tid; j < k; j += 256) {
+      cand_v[(long)r * k + j] = j == 0 ? 0.f : kFloatMin;
+      cand_i[(long)r * k + j] = j == 0 ? stop : (j - 1 < stop ? j - 1 : j);
+    }
+    return;
+  }
+  block_topk(pred, V, k, cand_v + (long)r * k, cand_i + (long)r * k, red, redi);
+}
+
+// allennlp beam restriction: per neuron, top-`beam` of the beam_prev*beam
+// summed candidates; backpointer = flat index / beam (trunc).
+__global__ __launch_bounds__(256) void beam_merge_kernel(
+    const float* __restrict__ cand_v, const int* __restrict__ cand_i,
+    const float* __restrict__ last_lp, int beam_prev, int beam,
+    float* __restrict__ new_lp, int* __restrict__ new_tok,
+    int* __restrict__ new_bp) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int nc = beam_prev * beam;
+  float* vals = sm;                 // [nc]
+  float* outv = sm + nc;            // [beam]
+  int* outi = (int*)(outv + beam);  // [beam]
+  float* red = (float*)(outi + beam);
+  int* redi = (int*)(red + 4);
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < nc; i += 256) {
+    const float lp = last_lp ? last_lp[(long)n * beam_prev + i / beam] : 0.f;
+    vals[i] = cand_v[(long)n * nc + i] + lp;
+  }
+  __syncthreads();
+  block_topk(vals, nc, beam, outv, outi, red, redi);
+  __syncthreads();
+  for (int j = tid; j < beam; j += 256) {
+    const int idx = outi[j];
+    new_lp[(long)n * beam + j] = outv[j];
+    new_tok[(long)n * beam + j] = cand_i[(long)n * nc + idx];
+    new_bp[(long)n * beam + j] = idx / beam;
+  }
+}
+
+// Index-only beam reorder (allennlp _update_state without moving features):
+// new row (n,j) takes h/c (and LM state) of old row n*beam_prev + bp, and its
+// next input token.  Also appends to the per-step history.
+__global__ void beam_reorder_kernel(
+    const int* __restrict__ new_tok, const int* __restrict__ new_bp, int n,
+    int beam_prev, int beam, int H, const float* __restrict__ h_src,
+    const float* __restrict__ c_src, float* __restrict__ h_dst,
+    float* __restrict__ c_dst, int lm_layers, int Hl, long lm_rows_src,
+    long lm_rows_dst, const float* __restrict__ hl_src,
+    const float* __restrict__ cl_src, float* __restrict__ hl_dst,
+    float* __restrict__ cl_dst, int64_t* __restrict__ tok_dst,
+    int* __restrict__ hist_tok, int* __restrict__ hist_bp) {
+  const int r = blockIdx.x;  // new row
+  const int nn = r / beam;
+  const int src = nn * beam_prev + new_bp[r];
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    h_dst[(long)r * H + j] = h_src[(long)src * H + j];
+    c_dst[(long)r * H + j] = c_src[(long)src * H + j];
+  }
+  for (int l = 0; l < lm_layers; ++l)
+    for (int j = threadIdx.x; j < Hl; j += blockDim.x) {
+      hl_dst[((long)l * lm_rows_dst + r) * Hl + j] =
+          hl_src[((long)l * lm_rows_src + src) * Hl + j];
+      cl_dst[((long)l * lm_rows_dst + r) * Hl + j] =
+          cl_src[((long)l * lm_rows_src + src) * Hl + j];
+    }
+  if (threadIdx.x == 0) {
+    tok_dst[r] = new_tok[r];
+    hist_tok[r] = new_tok[r];
+    hist_bp[r] = new_bp[r];
+  }
+}
+
+// Back-trace (allennlp _reconstruct_sequences) + T' per neuron group.
+__global__ void beam_finalize_kernel(const int* __restrict__ hist_tok,
+                                     const int* __restrict__ hist_bp, int n,
+                                     int beam, int T,
+                                     int64_t* __restrict__ beam_tokens) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n * beam) return;
+  const int nn = r / beam;
+  int j = r - nn * beam;
+  const long R = (long)n * beam;
+  for (int t = T - 1; t >= 0; --t) {
+    beam_tokens[(long)r * T + t] = hist_tok[t * R + nn * beam + j];
+    j = hist_bp[t * R + nn * beam + j];
+  }
+}
+
+// T'[g] = 1 + first step t whose chosen tokens are all <stop> over the group's
+// neurons (allennlp's early exit, evaluated per reference forward batch).
+__global__ void group_len_kernel(const int* __restrict__ hist_tok, int n,
+                                 int beam, int T, int group, int stop,
+                                 int32_t* __restrict__ out_len) {
+  const int g = blockIdx.x;
+  const int n0 = g * group, n1 = min(n, n0 + group);
+  const long R = (long)n * beam;
+  __shared__ int len;
+  if (threadIdx.x == 0) len = T;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    int all = 1;
+    for (int i = n0 * beam + threadIdx.x; i < n1 * beam; i += blockDim.x)
+      all &= hist_tok[t * R + i] == stop;
+    all = __syncthreads_and(all);
+    if (all) {
+      if (threadIdx.x == 0) len = t + 1;
+      break;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) out_len[g] = len;
+}
+
+// greedy bookkeeping (decoders.py:447,456-463)
+__global__ void greedy_record_kernel(const float* __restrict__ cand_v,
+                                     const int* __restrict__ cand_i,
+                                     const float* __restrict__ att, int n, int k,
+                                     int t, int T, int64_t* __restrict__ tokens,
+                                     float* __restrict__ scores,
+                                     float* __restrict__ attentions,
+                                     int64_t* __restrict__ next_tok) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  tokens[(long)r * T + t] = cand_i[r];
+  next_tok[r] = cand_i[r];
+  scores[r] = (t == 0 ? 0.f : scores[r]) + cand_v[r];
+  if (attentions)
+    for (int j = 0; j < k; ++j)
+      attentions[((long)r * T + t) * k + j] = att[(long)r * k + j];
+}
+
+__global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// LM: total[r] += alive[r] * valid * logp(target);  alive *= (input != stop)
+// (lms.py:93-100 including the j+1 off-by-one: `alive` lags one step).
+__global__ __launch_bounds__(256) void lm_accumulate_kernel(
+    const float* __restrict__ logits, int V, const int64_t* __restrict__ seqs,
+    long lds, int t, const int32_t* __restrict__ seq_len, int len_div, int stop,
+    float* __restrict__ alive, float* __restrict__ total) {
+  __shared__ float red[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long)r * V;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 256) mx = fmaxf(mx, x[i]);
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int i = tid; i < V; i += 256) s += expf(x[i] - mx);
+  s = block_sum(s, red);
+  if (tid == 0) {
+    const int64_t in = seqs[(long)r * lds + t], tgt = seqs[(long)r * lds + t + 1];
+    const bool valid = seq_len == nullptr || (t + 1) < seq_len[r / len_div];
+    const float a = t == 0 ? 1.f : alive[r];
+    float tot = t == 0 ? 0.f : total[r];
+    if (valid) tot += a * ((x[tgt] - mx) - logf(s));
+    total[r] = tot;
+    alive[r] = a * (in != stop ? 1.f : 0.f);
+  }
+}
+
+// seqs[r] = [start, beam_tokens[r][0..T)]
+__global__ void build_lm_seqs_kernel(const int64_t* __restrict__ beam_tokens,
+                                     long rows, int T, int64_t start,
+                                     int64_t* __restrict__ seqs) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= rows * (T + 1)) return;
+  const long r = idx / (T + 1);
+  const int t = idx - r * (T + 1);
+  seqs[idx] = t == 0 ? start : beam_tokens[r * T + t - 1];
+}
+
+__global__ void len_plus_one_kernel(const int32_t* in, int n, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] + 1;
+}
+
+// decoders.py:507-512 (rerank) / :493-494 (beam): pick per neuron.
+__global__ void rerank_select_kernel(const float* __restrict__ beam_scores,
+                                     const float* __restrict__ lm_scores,
+                                     float lambda, int n, int beam, int T,
+                                     const int64_t* __restrict__ beam_tokens,
+                                     int64_t* __restrict__ tokens,
+                                     float* __restrict__ scores) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int best = 0;
+  float bs = beam_scores[(long)i * beam];
+  if (lm_scores) {
+    bs = bs - lambda * lm_scores[(long)i * beam];
+    for (int j = 1; j < beam; ++j) {
+      const float s = beam_scores[(long)i * beam + j] -
+                      lambda * lm_scores[(long)i * beam + j];
+      if (s > bs) { bs = s; best = j; }
+    }
+  }
+  scores[i] = bs;
+  for (int t = 0; t < T; ++t)
+    tokens[(long)i * T + t] = beam_tokens[((long)i * beam + best) * T + t];
+}
+
+// ---------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------
+static inline int nblk(long total, int cap = 16384) {
+  long b = (total + 255) / 256;
+  return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+struct LmState {  // [layers][rows][Hl]
+  float *h = nullptr, *c = nullptr;
+  long rows = 0;
+};
+
+// One LM token step: returns logits (rows,V) in `logits`.
+static int lm_step(milan_ctx* c, const int64_t* tok, int rows, LmState& st,
+                   LmState& nx, float* emb, float* gates, float* logits,
+                   hipStream_t s) {
+  const milan_dims& d = c->d;
+  const int Hl = d.lm_hidden_size, El = d.lm_embedding_size, V = d.vocab_size;
+  hipLaunchKernelGGL(embed_kernel, dim3(nblk((long)rows * El)), dim3(256), 0, s,
+                     c->lm_embedding, tok, rows, El, emb, El);
+  const float* in = emb;
+  int in_dim = El;
+  for (int l = 0; l < d.lm_layers; ++l) {
+    const float* hl = st.h + (long)l * st.rows * Hl;
+    const float* cl = st.c + (long)l * st.rows * Hl;
+    float* hn = nx.h + (long)l * nx.rows * Hl;
+    float* cn = nx.c + (long)l * nx.rows * Hl;
+    MILAN_TRY(launch_gemm(linear_args(in, in_dim, c->lm_ih[l].w, c->lm_ih[l].b,
+                                      gates, 4 * Hl, rows, 4 * Hl, in_dim,
+                                      EPI_BIAS, c->zero), s));
+    MILAN_TRY(launch_gemm(linear_args(hl, Hl, c->lm_hh[l].w, c->lm_hh[l].b,
+                                      gates, 4 * Hl, rows, 4 * Hl, Hl,
+                                      EPI_BIAS_ADD, c->zero, gates, 4 * Hl), s));
+    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * Hl)),
+                       dim3(256), 0, s, gates, cl, rows, Hl, hn, cn);
+    in = hn;
+    in_dim = Hl;
+  }
+  MILAN_TRY(launch_gemm(linear_args(in, Hl, c->lm_out.w, c->lm_out.b, logits, V,
+                                    rows, V, Hl, EPI_BIAS, c->zero), s));
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+struct DecBuf {
+  float *keys, *pooled, *x, *h, *cc, *hn, *cn, *q, *att, *ctx, *gates, *logits;
+  float *lm_logits, *lm_emb, *lm_gates;
+  LmState lm[2];
+  float* cand_v; int* cand_i;
+  float* last_lp[2]; int *new_tok, *new_bp, *hist_tok, *hist_bp;
+  int64_t *tok, *seqs;
+  float *lm_alive, *lm_total;
+  int32_t* len1;
+};
+
+static void dec_plan(const milan_ctx* c, int n, int k, int beam, int T, bool lm,
+                     Arena& a, DecBuf* b) {
+  const milan_dims& d = c->d;
+  const size_t R = (size_t)n * beam;
+  const int F = d.feature_size, H = d.hidden_size, E = d.embedding_size,
+            A = d.attention_size, V = d.vocab_size;
+  b->keys = a.get<float>((size_t)n * k * A);
+  b->pooled = a.get<float>((size_t)n * F);
+  b->x = a.get<float>(R * (E + F));
+  b->h = a.get<float>(R * H); b->cc = a.get<float>(R * H);
+  b->hn = a.get<float>(R * H); b->cn = a.get<float>(R * H);
+  b->q = a.get<float>(R * A);
+  b->att = a.get<float>(R * k);
+  b->ctx = a.get<float>(R * F);
+  b->gates = a.get<float>(R * 4 * H);
+  b->logits = a.get<float>(R * V);
+  b->cand_v = a.get<float>(R * beam); b->cand_i = a.get<int>(R * beam);
+  b->last_lp[0] = a.get<float>(R); b->last_lp[1] = a.get<float>(R);
+  b->new_tok = a.get<int>(R); b->new_bp = a.get<int>(R);
+  b->hist_tok = a.get<int>(R * T); b->hist_bp = a.get<int>(R * T);
+  b->tok = a.get<int64_t>(R);
+  b->seqs = a.get<int64_t>(R * (T + 1));
+  b->len1 = a.get<int32_t>(2 * (size_t)n + 2);
+  b->lm_logits = nullptr;
+  if (lm) {
+    const int Hl = d.lm_hidden_size, El = d.lm_embedding_size;
+    b->lm_logits = a.get<float>(R * V);
+    b->lm_emb = a.get<float>(R * El);
+    b->lm_gates = a.get<float>(R * 4 * Hl);
+    for (int i = 0; i < 2; ++i) {
+      b->lm[i].h = a.get<float>(R * Hl * d.lm_layers);
+      b->lm[i].c = a.get<float>(R * Hl * d.lm_layers);
+      b->lm[i].rows = (long)R;
+    }
+    b->lm_alive = a.get<float>(R);
+    b->lm_total = a.get<float>(R);
+  }
+}
+
+size_t decoder_workspace(const milan_ctx* c, int n, int k, int beam, int length) {
+  Arena a; a.dry = true;
+  DecBuf b;
+  dec_plan(c, n, k, beam < 1 ? 1 : beam, length, c->d.has_lm != 0, a, &b);
+  return a.off;
+}
+
+static int check_dims(const milan_ctx* c, int k) {
+  MILAN_REQUIRE(c->finalized && c->lstm_ih.w != nullptr, MILAN_ERR_STATE,
+                "decoder weights not uploaded/finalized");
+  MILAN_REQUIRE(k >= 1 && k <= 64, MILAN_ERR_SHAPE,
+                "number of exemplars k=%d must be in 1..64", k);
+  MILAN_REQUIRE(c->d.feature_size % 4 == 0, MILAN_ERR_SHAPE,
+                "feature_size must be a multiple of 4");
+  return 0;
+}
+
+// keys = key_to_hidden(features): (n*k, F) x (A, F)^T
+static int project_keys(milan_ctx* c, const float* features, int nk, float* keys,
+                        hipStream_t s) {
+  const milan_dims& d = c->d;
+  return launch_gemm(linear_args(features, d.feature_size, c->k2h.w, c->k2h.b,
+                                 keys, d.attention_size, nk, d.attention_size,
+                                 d.feature_size, EPI_BIAS, c->zero), s);
+}
+
+static int init_state_impl(milan_ctx* c, const float* features, int n, int k,
+                           float* pooled, float* h, float* cc, hipStream_t s) {
+  const milan_dims& d = c->d;
+  const int F = d.feature_size, H = d.hidden_size;
+  hipLaunchKernelGGL(mean_k_kernel, dim3(nblk((long)n * F)), dim3(256), 0, s,
+                     features, n, k, F, pooled);
+  MILAN_TRY(launch_gemm(linear_args(pooled, F, c->init_h.w, c->init_h.b, h, H, n,
+                                    H, F, EPI_BIAS_TANH, c->zero), s));
+  MILAN_TRY(launch_gemm(linear_args(pooled, F, c->init_c.w, c->init_c.b, cc, H,
+                                    n, H, F, EPI_BIAS_TANH, c->zero), s));
+  return 0;
+}
+
+int decoder_init_state(milan_ctx* c, const float* features, int n, int k,
+                       float* h, float* cc, Arena& ws, hipStream_t s) {
+  MILAN_TRY(check_dims(c, k));
+  float* pooled = ws.get<float>((size_t)n * c->d.feature_size);
+  MILAN_REQUIRE(pooled, MILAN_ERR_WORKSPACE, "init_state: workspace too small");
+  return init_state_impl(c, features, n, k, pooled, h, cc, s);
+}
+
+// Everything of Decoder.step up to the vocabulary logits, for `rows` rows that
+// share features in groups of `rpn`.  x = [emb | gated] is built in b->x.
+static int step_core(milan_ctx* c, const float* features, const float* keys,
+                     int rows, int rpn, int k, const int64_t* tok,
+                     const float* h, const float* cc, float* hn, float* cn,
+                     DecBuf* b, hipStream_t s) {
+  const milan_dims& d = c->d;
+  const int F = d.feature_size, H = d.hidden_size, E = d.embedding_size,
+            A = d.attention_size, V = d.vocab_size;
+  const int ldx = E + F;
+  MILAN_TRY(launch_gemm(linear_args(h, H, c->q2h.w, c->q2h.b, b->q, A, rows, A, H,
+                                    EPI_BIAS, c->zero), s));
+  hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, b->q,
+                     keys, c->att_w, c->att_b, rows, rpn, k, A, b->att);
+  {
+    int gx = (F / 4 + 255) / 256;
+    hipLaunchKernelGGL(context_kernel, dim3(rows, gx), dim3(256), 0, s, b->att,
+                       features, rpn, k, F, b->ctx);
+  }
+  // gated = sigmoid(W_g h + b_g) * ctx  -> x[:, E:]
+  MILAN_TRY(launch_gemm(linear_args(h, H, c->gate.w, c->gate.b, b->x + E, ldx,
+                                    rows, F, H, EPI_BIAS_SIGMUL, c->zero, b->ctx,
+                                    F), s));
+  hipLaunchKernelGGL(embed_kernel, dim3(nblk((long)rows * E)), dim3(256), 0, s,
+                     c->embedding, tok, rows, E, b->x, ldx);
+  MILAN_TRY(launch_gemm(linear_args(b->x, ldx, c->lstm_ih.w, c->lstm_ih.b,
+                                    b->gates, 4 * H, rows, 4 * H, ldx, EPI_BIAS,
+                                    c->zero), s));
+  MILAN_TRY(launch_gemm(linear_args(h, H, c->lstm_hh.w, c->lstm_hh.b, b->gates,
+                                    4 * H, rows, 4 * H, H, EPI_BIAS_ADD, c->zero,
+                                    b->gates, 4 * H), s));
+  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * H)), dim3(256),
+                     0, s, b->gates, cc, rows, H, hn, cn);
+  MILAN_TRY(launch_gemm(linear_args(hn, H, c->out.w, c->out.b, b->logits, V, rows,
+                                    V, H, EPI_BIAS, c->zero), s));
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static size_t row_select_lds(int V) { return sizeof(float) * (V + 8); }
+
+static int launch_row_select(const float* logits, const float* lm_logits,
+                             float lambda, int rows, int V, int k,
+                             const int64_t* last_tok, int stop, float* cand_v,
+                             int* cand_i, float* pred_out, long pred_stride,
+                             hipStream_t s) {
+  const size_t lds = row_select_lds(V);
+  MILAN_REQUIRE(lds <= 160 * 1024, MILAN_ERR_SHAPE,
+                "vocab_size %d too large for the row-select kernel", V);
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(row_select_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  hipLaunchKernelGGL(row_select_kernel, dim3(rows), dim3(256), lds, s, logits,
+                     lm_logits, lambda, V, k, last_tok, stop, cand_v, cand_i,
+                     pred_out, pred_stride);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int decoder_step(milan_ctx* c, const float* features, int rows, int k,
+                 const int64_t* tokens, const float* h, const float* cc,
+                 float* h_lm, float* c_lm, float temperature, float* predictions,
+                 float* attentions, float* h_out, float* c_out, Arena& ws,
+                 hipStream_t s) {
+  MILAN_TRY(check_dims(c, k));
+  const bool mi = h_lm != nullptr;
+  MILAN_REQUIRE((h_lm == nullptr) == (c_lm == nullptr), MILAN_ERR_ARG,
+                "state must have both h_lm and c_lm or neither");
+  MILAN_REQUIRE(!mi || c->d.has_lm, MILAN_ERR_NO_LM,
+                "state has h_lm or c_lm, but decoder has no lm");
+  DecBuf b;
+  dec_plan(c, rows, k, 1, 1, mi, ws, &b);
+  // per-row keys: the public step takes per-row features (un-hoisted API)
+  MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
+                "step: workspace too small (%zu needed)", ws.off);
+  MILAN_TRY(project_keys(c, features, rows * k, b.keys, s));
+  MILAN_TRY(step_core(c, features, b.keys, rows, 1, k, tokens, h, cc, h_out,
+                      c_out, &b, s));
+  const float* lm_logits = nullptr;
+  if (mi) {
+    LmState st{h_lm, c_lm, rows};
+    MILAN_TRY(lm_step(c, tokens, rows, st, b.lm[0], b.lm_emb, b.lm_gates,
+                      b.lm_logits, s));
+    const size_t bytes = sizeof(float) * (size_t)rows * c->d.lm_hidden_size *
+                         c->d.lm_layers;
+    MILAN_CHECK_HIP(hipMemcpyAsync(h_lm, b.lm[0].h, bytes, hipMemcpyDeviceToDevice, s));
+    MILAN_CHECK_HIP(hipMemcpyAsync(c_lm, b.lm[0].c, bytes, hipMemcpyDeviceToDevice, s));
+    lm_logits = b.lm_logits;
+  }
+  MILAN_TRY(launch_row_select(b.logits, lm_logits, temperature, rows,
+                              c->d.vocab_size, 0, nullptr, 0, nullptr, nullptr,
+                              predictions, c->d.vocab_size, s));
+  if (attentions)
+    MILAN_CHECK_HIP(hipMemcpyAsync(attentions, b.att,
+                                   sizeof(float) * (size_t)rows * k,
+                                   hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+__global__ void gather_col_kernel(const int64_t* __restrict__ seqs, long rows,
+                                  long lds, int t, int64_t* __restrict__ out) {
+  const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (r < rows) out[r] = seqs[r * lds + t];
+}
+
+// LanguageModel.forward(reduce=True), lms.py:58-101.  seq_len (device, may be
+// null) is indexed by row / len_div.
+static int lm_score_impl(milan_ctx* c, const int64_t* seqs, int rows, int L,
+                         const int32_t* seq_len, int len_div, float* total,
+                         DecBuf* b, hipStream_t s) {
+  const milan_dims& d = c->d;
+  MILAN_REQUIRE(d.has_lm && c->lm_out.w, MILAN_ERR_NO_LM,
+                "cannot use MI/rerank decoding without an LM");
+  const size_t st_bytes =
+      sizeof(float) * (size_t)b->lm[0].rows * d.lm_hidden_size * d.lm_layers;
+  MILAN_CHECK_HIP(hipMemsetAsync(b->lm[0].h, 0, st_bytes, s));
+  MILAN_CHECK_HIP(hipMemsetAsync(b->lm[0].c, 0, st_bytes, s));
+  if (L < 2) {
+    MILAN_CHECK_HIP(hipMemsetAsync(total, 0, sizeof(float) * rows, s));
+    return 0;
+  }
+  int cur = 0;
+  for (int t = 0; t + 1 < L; ++t) {
+    hipLaunchKernelGGL(gather_col_kernel, dim3(nblk(rows)), dim3(256), 0, s, seqs,
+                       (long)rows, (long)L, t, b->tok);
+    MILAN_TRY(lm_step(c, b->tok, rows, b->lm[cur], b->lm[cur ^ 1], b->lm_emb,
+                      b->lm_gates, b->lm_logits, s));
+    hipLaunchKernelGGL(lm_accumulate_kernel, dim3(rows), dim3(256), 0, s,
+                       b->lm_logits, d.vocab_size, seqs, (long)L, t, seq_len,
+                       len_div, d.stop_index, b->lm_alive, total);
+    cur ^= 1;
+  }
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int decoder_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
+                     const int32_t* seq_len, float* out, Arena& ws,
+                     hipStream_t s) {
+  MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
+  MILAN_REQUIRE(c->d.has_lm && c->lm_out.w, MILAN_ERR_NO_LM,
+                "cannot use MI/rerank decoding without an LM");
+  MILAN_REQUIRE(rows > 0 && L >= 1, MILAN_ERR_SHAPE, "lm_score: empty input");
+  DecBuf b;
+  dec_plan(c, rows, 1, 1, 1, true, ws, &b);
+  MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
+                "lm_score: workspace too small (%zu needed)", ws.off);
+  return lm_score_impl(c, seqs, rows, L, seq_len, 1, out, &b, s);
+}
+
+int decoder_decode(milan_ctx* c, const float* features, int n, int k,
+                   int strategy, int length, int beam, int mi, float temperature,
+                   int group_size, int64_t* tokens, float* scores,
+                   float* predictions, float* attentions, int64_t* beam_tokens,
+                   float* beam_scores, int32_t* out_len, Arena& ws,
+                   hipStream_t s) {
+  MILAN_TRY(check_dims(c, k));
+  const milan_dims& d = c->d;
+  const int H = d.hidden_size, V = d.vocab_size;
+  MILAN_REQUIRE(strategy == MILAN_GREEDY || strategy == MILAN_BEAM ||
+                    strategy == MILAN_RERANK,
+                MILAN_ERR_ARG, "unknown strategy: %d", strategy);
+  MILAN_REQUIRE(!(mi && strategy == MILAN_RERANK), MILAN_ERR_ARG,
+                "cannot set `mi=` decoding when reranking");
+  MILAN_REQUIRE(!(mi || strategy == MILAN_RERANK) || d.has_lm, MILAN_ERR_NO_LM,
+                "cannot use MI/rerank decoding without an LM");
+  MILAN_REQUIRE(n > 0 && length > 0, MILAN_ERR_SHAPE, "decode: empty batch");
+  const bool greedy = strategy == MILAN_GREEDY;
+  if (greedy) beam = 1;
+  MILAN_REQUIRE(beam >= 1 && beam <= V, MILAN_ERR_ARG,
+                "beam_size %d must be in 1..vocab_size", beam);
+  MILAN_REQUIRE(greedy || (beam_tokens && beam_scores), MILAN_ERR_ARG,
+                "beam search needs beam_tokens and beam_scores outputs");
+  MILAN_REQUIRE(tokens && scores, MILAN_ERR_ARG, "tokens/scores outputs required");
+  if (group_size <= 0) group_size = n;
+  const bool need_lm = mi || strategy == MILAN_RERANK;
+  DecBuf b;
+  dec_plan(c, n, k, beam, length, need_lm, ws, &b);
+  MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
+                "decode: workspace too small (%zu needed, %zu given)", ws.off,
+                ws.size);
+  const int R = n * beam;
+  const int Hl = d.lm_hidden_size;
+
+  MILAN_TRY(project_keys(c, features, n * k, b.keys, s));
+  MILAN_TRY(init_state_impl(c, features, n, k, b.pooled, b.h, b.cc, s));
+  hipLaunchKernelGGL(fill_i64_kernel, dim3(nblk(n)), dim3(256), 0, s, b.tok,
+                     (long)n, (int64_t)d.start_index);
+  int lmcur = 0;
+  if (mi) {
+    const size_t st_bytes = sizeof(float) * (size_t)R * Hl * d.lm_layers;
+    MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].h, 0, st_bytes, s));
+    MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].c, 0, st_bytes, s));
+  }
+
+  if (greedy) {
+    float *h = b.h, *cc = b.cc, *hn = b.hn, *cn = b.cn;
+    for (int t = 0; t < length; ++t) {
+      MILAN_TRY(step_core(c, features, b.keys, n, 1, k, b.tok, h, cc, hn, cn, &b, s));
+      const float* lm_logits = nullptr;
+      if (mi) {
+        MILAN_TRY(lm_step(c, b.tok, n, b.lm[lmcur], b.lm[lmcur ^ 1], b.lm_emb,
+                          b.lm_gates, b.lm_logits, s));
+        lmcur ^= 1;
+        lm_logits = b.lm_logits;
+      }
+      MILAN_TRY(launch_row_select(
+          b.logits, lm_logits, temperature, n, V, 1, nullptr, 0, b.cand_v,
+          b.cand_i, predictions ? predictions + (long)t * V : nullptr,
+          (long)length * V, s));
+      hipLaunchKernelGGL(greedy_record_kernel, dim3(nblk(n)), dim3(256), 0, s,
+                         b.cand_v, b.cand_i, b.att, n, k, t, length, tokens,
+                         scores, attentions, b.tok);
+      float* tmp = h; h = hn; hn = tmp;
+      tmp = cc; cc = cn; cn = tmp;
+    }
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+
+  // ---- beam search (allennlp 2.10 semantics, fixed `length` steps) ----------
+  const size_t merge_lds = sizeof(float) * ((size_t)beam * beam + 2 * beam + 16);
+  MILAN_REQUIRE(merge_lds <= 64 * 1024, MILAN_ERR_ARG,
+                "beam_size %d too large for the merge kernel", beam);
+  int beam_prev = 1, rows = n, lpcur = 0;
+  for (int t = 0; t < length; ++t) {
+    MILAN_TRY(step_core(c, features, b.keys, rows, beam_prev, k, b.tok, b.h, b.cc,
+                        b.hn, b.cn, &b, s));
+    const float* lm_logits = nullptr;
+    if (mi) {
+      b.lm[lmcur].rows = b.lm[lmcur ^ 1].rows = R;
+      MILAN_TRY(lm_step(c, b.tok, rows, b.lm[lmcur], b.lm[lmcur ^ 1], b.lm_emb,
+                        b.lm_gates, b.lm_logits, s));
+      lm_logits = b.lm_logits;
+    }
+    MILAN_TRY(launch_row_select(b.logits, lm_logits, temperature, rows, V, beam,
+                                t == 0 ? nullptr : b.tok, d.stop_index, b.cand_v,
+                                b.cand_i, nullptr, 0, s));
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(n), dim3(256), merge_lds, s,
+                       b.cand_v, b.cand_i, t == 0 ? nullptr : b.last_lp[lpcur],
+                       beam_prev, beam, b.last_lp[lpcur ^ 1], b.new_tok, b.new_bp);
+    lpcur ^= 1;
+    // reorder: (hn,cn)[src] -> (h,cc)[r]; LM new state -> the other LM buffer
+    hipLaunchKernelGGL(
+        beam_reorder_kernel, dim3(R), dim3(128), 0, s, b.new_tok, b.new_bp, n,
+        beam_prev, beam, H, b.hn, b.cn, b.h, b.cc, mi ? d.lm_layers : 0, Hl,
+        (long)R, (long)R, mi ? b.lm[lmcur ^ 1].h : nullptr,
+        mi ? b.lm[lmcur ^ 1].c : nullptr, mi ? b.lm[lmcur].h : nullptr,
+        mi ? b.lm[lmcur].c : nullptr, b.tok, b.hist_tok + (long)t * R,
+        b.hist_bp + (long)t * R);
+    beam_prev = beam;
+    rows = R;
+  }
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3(nblk(R)), dim3(256), 0, s,
+                     b.hist_tok, b.hist_bp, n, beam, length, beam_tokens);
+  MILAN_CHECK_HIP(hipMemcpyAsync(beam_scores, b.last_lp[lpcur],
+                                 sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+  const int groups = (n + group_size - 1) / group_size;
+  int32_t* lens = out_len ? out_len : b.len1 + n + 1;  // scratch if not wanted
+  hipLaunchKernelGGL(group_len_kernel, dim3(groups), dim3(256), 0, s, b.hist_tok,
+                     n, beam, length, group_size, d.stop_index, lens);
+  const float* lm_scores = nullptr;
+  if (strategy == MILAN_RERANK) {
+    hipLaunchKernelGGL(build_lm_seqs_kernel, dim3(nblk((long)R * (length + 1))),
+                       dim3(256), 0, s, beam_tokens, (long)R, length,
+                       (int64_t)d.start_index, b.seqs);
+    hipLaunchKernelGGL(len_plus_one_kernel, dim3(nblk(groups)), dim3(256), 0, s,
+                       lens, groups, b.len1);
+    b.lm[0].rows = b.lm[1].rows = R;
+    MILAN_TRY(lm_score_impl(c, b.seqs, R, length + 1, b.len1, beam * group_size,
+                            b.lm_total, &b, s));
+    lm_scores = b.lm_total;
+  }
+  hipLaunchKernelGGL(rerank_select_kernel, dim3(nblk(n)), dim3(256), 0, s,
+                     beam_scores, lm_scores, temperature, n, beam, length,
+                     beam_tokens, tokens, scores);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace milan

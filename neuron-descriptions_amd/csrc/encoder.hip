@@ -1,0 +1,515 @@
+// Masked-exemplar pyramid encoder: PyramidConvEncoder.forward
+// (reference src/milan/encoders.py:286-320) over a torchvision bottleneck
+// ResNet trunk (call site encoders.py:274,346-350).
+//
+// Data layout in HBM: activations are NHWC fp32 (a conv tap = contiguous Cin
+// run = one coalesced 16-B chunk per lane for the implicit GEMM); the network
+// input is NHWC4 (RGB + a zero lane) so the 7x7 stem is the same kernel with
+// Cin = 4.  Eval-mode BatchNorm is folded into the conv weights/bias at
+// finalize time, except for the stem whose RAW output is a pyramid tap
+// (nethook retains 'conv1' before bn1/relu, src/deps/netdissect/nethook.py:
+// 226-235); bn1+relu+maxpool run as one fused kernel.
+#include "common.h"
+
+namespace milan {
+
+static constexpr float kBnEps = 1e-5f;  // torchvision 0.12 BatchNorm2d default
+
+// ---------------------------------------------------------------------------
+// weight packing (one-time)
+// ---------------------------------------------------------------------------
+// OIHW conv weight (+ optional eval-BN) -> [Cout][Kp], k = (kh*KW+kw)*CinP + i.
+__global__ void pack_conv_kernel(const float* __restrict__ w, int cout, int cin,
+                                 int cinp, int kh, int kw, int kp,
+                                 const float* __restrict__ gamma,
+                                 const float* __restrict__ beta,
+                                 const float* __restrict__ mean,
+                                 const float* __restrict__ var,
+                                 float* __restrict__ wp,
+                                 float* __restrict__ bias) {
+  const long total = (long)cout * kp;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int o = idx / kp, k = idx - (long)o * kp;
+    const int tap = k / cinp, i = k - tap * cinp;
+    float v = 0.f;
+    if (tap < kh * kw && i < cin) {
+      const int y = tap / kw, x = tap - y * kw;
+      v = w[(((long)o * cin + i) * kh + y) * kw + x];
+      if (gamma) v *= gamma[o] / sqrtf(var[o] + kBnEps);
+    }
+    wp[idx] = v;
+    if (bias && k == 0) {
+      const float sc = gamma[o] / sqrtf(var[o] + kBnEps);
+      bias[o] = beta[o] - mean[o] * sc;
+    }
+  }
+}
+
+__global__ void bn_affine_kernel(const float* gamma, const float* beta,
+                                 const float* mean, const float* var, int c,
+                                 float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c) {
+    const float sc = gamma[i] / sqrtf(var[i] + kBnEps);
+    scale[i] = sc;
+    shift[i] = beta[i] - mean[i] * sc;
+  }
+}
+
+static const Tensor* find(milan_ctx* c, const std::string& name) {
+  auto it = c->raw.find(name);
+  return it == c->raw.end() ? nullptr : &it->second;
+}
+
+static int pack_conv(milan_ctx* c, const std::string& conv,
+                     const std::string& bn, int stride, int pad, ConvW* out,
+                     hipStream_t s) {
+  const Tensor* w = find(c, conv + ".weight");
+  MILAN_REQUIRE(w && w->shape.size() == 4, MILAN_ERR_STATE,
+                "missing conv weight %s.weight", conv.c_str());
+  const float *g = nullptr, *b = nullptr, *m = nullptr, *v = nullptr;
+  if (!bn.empty()) {
+    const Tensor *tg = find(c, bn + ".weight"), *tb = find(c, bn + ".bias"),
+                 *tm = find(c, bn + ".running_mean"),
+                 *tv = find(c, bn + ".running_var");
+    MILAN_REQUIRE(tg && tb && tm && tv, MILAN_ERR_STATE,
+                  "missing batchnorm tensors %s.*", bn.c_str());
+    MILAN_REQUIRE(tg->numel() == w->shape[0], MILAN_ERR_SHAPE,
+                  "%s channels != %s out channels", bn.c_str(), conv.c_str());
+    g = tg->dev; b = tb->dev; m = tm->dev; v = tv->dev;
+  }
+  out->cout = (int)w->shape[0];
+  out->cin = ((int)w->shape[1] + 3) / 4 * 4;
+  out->kh = (int)w->shape[2];
+  out->kw = (int)w->shape[3];
+  out->stride = stride;
+  out->pad = pad;
+  out->K = out->kh * out->kw * out->cin;
+  out->Kp = (out->K + 31) / 32 * 32;
+  MILAN_TRY(dev_alloc(c, (void**)&out->w,
+                      sizeof(float) * (size_t)out->cout * out->Kp));
+  if (g) MILAN_TRY(dev_alloc(c, (void**)&out->bias, sizeof(float) * out->cout));
+  const long total = (long)out->cout * out->Kp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w->dev,
+                     out->cout, (int)w->shape[1], out->cin, out->kh, out->kw,
+                     out->Kp, g, b, m, v, out->w, out->bias);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
+                    float* wp, hipStream_t s) {
+  const int cinp = (cin + 3) / 4 * 4;
+  const int kp = (kh * kw * cinp + 31) / 32 * 32;
+  const long total = (long)cout * kp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w_oihw,
+                     cout, cin, cinp, kh, kw, kp, nullptr, nullptr, nullptr,
+                     nullptr, wp, nullptr);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int encoder_finalize(milan_ctx* c, hipStream_t s) {
+  const std::string p = "encoder.encoder.model.";
+  if (!find(c, p + "conv1.weight")) return 0;  // decoder-only context
+  MILAN_TRY(pack_conv(c, p + "conv1", "", 2, 3, &c->stem, s));
+  MILAN_REQUIRE(c->stem.cout == c->d.trunk_width, MILAN_ERR_SHAPE,
+                "stem width %d != dims.trunk_width %d", c->stem.cout,
+                c->d.trunk_width);
+  {
+    const Tensor *tg = find(c, p + "bn1.weight"), *tb = find(c, p + "bn1.bias"),
+                 *tm = find(c, p + "bn1.running_mean"),
+                 *tv = find(c, p + "bn1.running_var");
+    MILAN_REQUIRE(tg && tb && tm && tv, MILAN_ERR_STATE, "missing bn1.*");
+    const int w = c->stem.cout;
+    MILAN_TRY(dev_alloc(c, (void**)&c->bn1_scale, sizeof(float) * w));
+    MILAN_TRY(dev_alloc(c, (void**)&c->bn1_shift, sizeof(float) * w));
+    hipLaunchKernelGGL(bn_affine_kernel, dim3((w + 255) / 256), dim3(256), 0, s,
+                       tg->dev, tb->dev, tm->dev, tv->dev, w, c->bn1_scale,
+                       c->bn1_shift);
+  }
+  for (int li = 0; li < 4; ++li) {
+    c->blocks[li].clear();
+    for (int bi = 0; bi < c->d.trunk_blocks[li]; ++bi) {
+      Bottleneck b;
+      const std::string q =
+          p + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+      const int stride = (bi == 0 && li > 0) ? 2 : 1;
+      MILAN_TRY(pack_conv(c, q + "conv1", q + "bn1", 1, 0, &b.c1, s));
+      MILAN_TRY(pack_conv(c, q + "conv2", q + "bn2", stride, 1, &b.c2, s));
+      MILAN_TRY(pack_conv(c, q + "conv3", q + "bn3", 1, 0, &b.c3, s));
+      b.has_down = find(c, q + "downsample.0.weight") != nullptr;
+      MILAN_REQUIRE(b.has_down == (bi == 0), MILAN_ERR_STATE,
+                    "unexpected downsample layout at %s", q.c_str());
+      if (b.has_down)
+        MILAN_TRY(pack_conv(c, q + "downsample.0", q + "downsample.1", stride,
+                            0, &b.down, s));
+      c->blocks[li].push_back(b);
+    }
+  }
+  if (const Tensor* t = find(c, "encoder.mean")) {
+    MILAN_CHECK_HIP(hipMemcpyAsync(c->mean, t->dev, 3 * sizeof(float),
+                                   hipMemcpyDeviceToHost, s));
+  }
+  if (const Tensor* t = find(c, "encoder.std")) {
+    MILAN_CHECK_HIP(hipMemcpyAsync(c->stdv, t->dev, 3 * sizeof(float),
+                                   hipMemcpyDeviceToHost, s));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// input conversion: NCHW u8/f32 -> normalised NHWC4 f32
+// ---------------------------------------------------------------------------
+// x = float(u8) * float32(1/255)  (src/milannotations/datasets.py:191-197 via
+// renormalize.py:119-136: a multiply, not a divide), then (x - mean) / std
+// (src/milan/encoders.py:295).
+template <typename T>
+__global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
+                                  int hw, float m0, float m1, float m2,
+                                  float s0, float s1, float s2,
+                                  float4* __restrict__ out) {
+  const float inv255 = (float)(1.0 / 255.0);
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n_pix_total;
+       p += (long)gridDim.x * blockDim.x) {
+    const long n = p / hw, r = p - n * hw;
+    const T* base = img + n * 3 * hw + r;
+    float v0, v1, v2;
+    if constexpr (sizeof(T) == 1) {
+      v0 = (float)base[0] * inv255;
+      v1 = (float)base[hw] * inv255;
+      v2 = (float)base[2 * (long)hw] * inv255;
+    } else {
+      v0 = base[0]; v1 = base[hw]; v2 = base[2 * (long)hw];
+    }
+    out[p] = make_float4((v0 - m0) / s0, (v1 - m1) / s1, (v2 - m2) / s2, 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stem tail: y = maxpool3x3/2,pad1( relu( x*scale + shift ) ), NHWC
+// ---------------------------------------------------------------------------
+__global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, int n,
+                                       int H, int W, int C4, int Ho, int Wo,
+                                       const float4* __restrict__ scale,
+                                       const float4* __restrict__ shift,
+                                       float4* __restrict__ y) {
+  const long total = (long)n * Ho * Wo * C4;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int c = idx % C4;
+    long t = idx / C4;
+    const int wo = t % Wo; t /= Wo;
+    const int ho = t % Ho;
+    const long img = t / Ho;
+    const float4 sc = scale[c], sh = shift[c];
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * 2 - 1 + dy;
+      if (hi < 0 || hi >= H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * 2 - 1 + dx;
+        if (wi < 0 || wi >= W) continue;
+        const float4 v = x[((img * H + hi) * W + wi) * C4 + c];
+        best.x = fmaxf(best.x, fmaxf(v.x * sc.x + sh.x, 0.f));
+        best.y = fmaxf(best.y, fmaxf(v.y * sc.y + sh.y, 0.f));
+        best.z = fmaxf(best.z, fmaxf(v.z * sc.z + sh.z, 0.f));
+        best.w = fmaxf(best.w, fmaxf(v.w * sc.w + sh.w, 0.f));
+      }
+    }
+    y[idx] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// mask pyramid: bilinear resize (align_corners=False) + normalise + compact
+// ---------------------------------------------------------------------------
+// src/milan/encoders.py:303-314.  One workgroup per (image, level).  Output:
+// an ORDERED list of (pixel, weight) for the non-zero weights plus its length,
+// so the pooling kernel touches only feature pixels under the mask.
+struct Levels {
+  int h[5], w[5];
+  long off[5];  // offset (entries) of level l inside one image's list
+  long per_image;
+};
+
+static constexpr int kMaxLevelPixels = 12800;
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_pyramid_kernel(
+    const T* __restrict__ masks, int H, int W, Levels lv,
+    int* __restrict__ list_idx, float* __restrict__ list_w,
+    int* __restrict__ list_n) {
+  __shared__ float wts[kMaxLevelPixels];
+  __shared__ float red_sum[4], red_max[4];
+  const int img = blockIdx.x, l = blockIdx.y;
+  const int h = lv.h[l], w = lv.w[l], P = h * w;
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  float lsum = 0.f, lmax = 0.f;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    float v;
+    if (masks == nullptr) {
+      v = 1.f;  // encoders.py:292-293: no masks == all ones
+    } else {
+      const T* m = masks + (long)img * H * W;
+      const int oy = p / w, ox = p - oy * w;
+      // ATen upsample_bilinear2d, align_corners=false
+      float fy = ((float)oy + 0.5f) * sy - 0.5f; fy = fy < 0.f ? 0.f : fy;
+      float fx = ((float)ox + 0.5f) * sx - 0.5f; fx = fx < 0.f ? 0.f : fx;
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+      const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+      const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+      const float v00 = (float)m[y0 * W + x0], v01 = (float)m[y0 * W + x1];
+      const float v10 = (float)m[y1 * W + x0], v11 = (float)m[y1 * W + x1];
+      v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+    }
+    wts[p] = v;
+    lsum += v;
+    lmax = fmaxf(lmax, fabsf(v));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lsum += __shfl_down(lsum, o);
+    lmax = fmaxf(lmax, __shfl_down(lmax, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red_sum[threadIdx.x >> 6] = lsum;
+    red_max[threadIdx.x >> 6] = lmax;
+  }
+  __syncthreads();
+  const float total = (red_sum[0] + red_sum[1]) + (red_sum[2] + red_sum[3]);
+  const float amax = fmaxf(fmaxf(red_max[0], red_max[1]),
+                           fmaxf(red_max[2], red_max[3]));
+  // valid = not all isclose(ms, 0) (atol 1e-8): only then normalise.
+  const bool valid = amax > 1e-8f;
+  // ordered compaction by wave 0
+  if (threadIdx.x < 64) {
+    const long base = (long)img * lv.per_image + lv.off[l];
+    int count = 0;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+      const int p = p0 + threadIdx.x;
+      float v = p < P ? wts[p] : 0.f;
+      if (valid) v = v / total;
+      const bool nz = (p < P) && (v != 0.f);
+      const unsigned long long mask = __ballot(nz);
+      const int pos =
+          count + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
+      if (nz) {
+        list_idx[base + pos] = p;
+        list_w[base + pos] = v;
+      }
+      count += __popcll(mask);
+    }
+    if (threadIdx.x == 0) list_n[img * 5 + l] = count;
+  }
+}
+
+// features[img][col_off + c] = sum_p w[p] * tap[img][p][c]   (encoders.py:317)
+// grid (n_images, ceil(C/64)); 4 waves split the pixel list, lane = channel.
+__global__ __launch_bounds__(256) void masked_pool_kernel(
+    const float* __restrict__ tap, int P, int C, int level, Levels lv,
+    const int* __restrict__ list_idx, const float* __restrict__ list_w,
+    const int* __restrict__ list_n, float* __restrict__ features, int fstride,
+    int col_off) {
+  __shared__ float part[4][64];
+  const int img = blockIdx.x;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int phase = threadIdx.x >> 6;
+  const long base = (long)img * lv.per_image + lv.off[level];
+  const int cnt = list_n[img * 5 + level];
+  const float* t = tap + (long)img * P * C + c;
+  float acc0 = 0.f, acc1 = 0.f;
+  if (c < C) {
+    int i = phase;
+    for (; i + 4 < cnt; i += 8) {
+      const int p0 = list_idx[base + i], p1 = list_idx[base + i + 4];
+      const float w0 = list_w[base + i], w1 = list_w[base + i + 4];
+      acc0 += w0 * t[(long)p0 * C];
+      acc1 += w1 * t[(long)p1 * C];
+    }
+    if (i < cnt) acc0 += list_w[base + i] * t[(long)list_idx[base + i] * C];
+  }
+  part[phase][threadIdx.x & 63] = acc0 + acc1;
+  __syncthreads();
+  if (phase == 0 && c < C) {
+    features[(long)img * fstride + col_off + c] =
+        (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+        (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// driver
+// ---------------------------------------------------------------------------
+struct EncPlan {
+  Levels lv;
+  int h1, w1, hp, wp;
+  float *in4, *raw, *x0, *x1, *ds, *t1, *t2;
+  int *list_idx, *list_n;
+  float* list_w;
+};
+
+static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+
+static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) {
+  const int wd = c->d.trunk_width;
+  pl->h1 = conv_out(H, 7, 2, 3); pl->w1 = conv_out(W, 7, 2, 3);
+  pl->hp = conv_out(pl->h1, 3, 2, 1); pl->wp = conv_out(pl->w1, 3, 2, 1);
+  Levels& lv = pl->lv;
+  lv.h[0] = pl->h1; lv.w[0] = pl->w1;
+  lv.h[1] = pl->hp; lv.w[1] = pl->wp;
+  for (int l = 2; l < 5; ++l) {
+    lv.h[l] = conv_out(lv.h[l - 1], 3, 2, 1);
+    lv.w[l] = conv_out(lv.w[l - 1], 3, 2, 1);
+  }
+  long off = 0;
+  for (int l = 0; l < 5; ++l) { lv.off[l] = off; off += (long)lv.h[l] * lv.w[l]; }
+  lv.per_image = off;
+  const size_t p0 = (size_t)n * pl->hp * pl->wp;  // pixels at layer1 resolution
+  pl->in4 = a.get<float>((size_t)n * H * W * 4);
+  pl->raw = a.get<float>((size_t)n * pl->h1 * pl->w1 * wd);
+  pl->x0 = a.get<float>(p0 * wd * 4);
+  pl->x1 = a.get<float>(p0 * wd * 4);
+  pl->ds = a.get<float>(p0 * wd * 4);
+  pl->t1 = a.get<float>(p0 * wd * 2);
+  pl->t2 = a.get<float>(p0 * wd);
+  pl->list_idx = a.get<int>((size_t)n * lv.per_image);
+  pl->list_w = a.get<float>((size_t)n * lv.per_image);
+  pl->list_n = a.get<int>((size_t)n * 5);
+  return 0;
+}
+
+size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W) {
+  Arena a; a.dry = true;
+  EncPlan pl;
+  plan(c, n_images, H, W, a, &pl);
+  return a.off;
+}
+
+static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
+                          float* out, int epi, const float* aux,
+                          const float* zero, int* Ho, int* Wo) {
+  GemmArgs g{};
+  *Ho = conv_out(H, cw.kh, cw.stride, cw.pad);
+  *Wo = conv_out(W, cw.kw, cw.stride, cw.pad);
+  g.A = in; g.W = cw.w; g.bias = cw.bias; g.aux = aux; g.C = out;
+  g.M = n * (*Ho) * (*Wo); g.N = cw.cout; g.K = cw.K; g.Kp = cw.Kp;
+  g.ldc = cw.cout; g.ldaux = cw.cout;
+  g.H = H; g.Wd = W; g.Cin = cw.cin; g.Ho = *Ho; g.Wo = *Wo;
+  g.KH = cw.kh; g.KW = cw.kw; g.stride = cw.stride; g.pad = cw.pad;
+  g.a_pix_stride = cw.cin;
+  g.a_img_stride = (long)H * W * cw.cin;
+  g.epilogue = epi; g.zero = zero;
+  return g;
+}
+
+int encoder_run(milan_ctx* c, const void* images, int image_dtype,
+                const void* masks, int mask_dtype, int n, int H, int W,
+                float* features, Arena& ws, hipStream_t s) {
+  MILAN_REQUIRE(c->stem.w != nullptr, MILAN_ERR_STATE,
+                "encoder weights were not uploaded");
+  MILAN_REQUIRE(n > 0 && H >= 32 && W >= 32, MILAN_ERR_SHAPE,
+                "encode: need n>0 and H,W>=32 (got n=%d H=%d W=%d)", n, H, W);
+  EncPlan pl;
+  plan(c, n, H, W, ws, &pl);
+  MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
+                "encode: workspace too small (%zu needed, %zu given)", ws.off,
+                ws.size);
+  MILAN_REQUIRE(pl.lv.h[0] * pl.lv.w[0] <= kMaxLevelPixels, MILAN_ERR_SHAPE,
+                "encode: image %dx%d too large for the mask pyramid kernel", H,
+                W);
+  const int wd = c->d.trunk_width;
+  const int F = c->d.feature_size;
+
+  // 1. masks -> per-level normalised sparse weight lists
+  if (masks == nullptr || mask_dtype == MILAN_DTYPE_U8)
+    hipLaunchKernelGGL(mask_pyramid_kernel<uint8_t>, dim3(n, 5), dim3(256), 0, s,
+                       (const uint8_t*)masks, H, W, pl.lv, pl.list_idx,
+                       pl.list_w, pl.list_n);
+  else
+    hipLaunchKernelGGL(mask_pyramid_kernel<float>, dim3(n, 5), dim3(256), 0, s,
+                       (const float*)masks, H, W, pl.lv, pl.list_idx, pl.list_w,
+                       pl.list_n);
+  MILAN_CHECK_HIP(hipGetLastError());
+
+  // 2. images -> normalised NHWC4
+  {
+    const long np = (long)n * H * W;
+    const int blocks = (int)((np + 255) / 256 < 8192 ? (np + 255) / 256 : 8192);
+    if (image_dtype == MILAN_DTYPE_U8)
+      hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
+                         s, (const uint8_t*)images, np, H * W, c->mean[0],
+                         c->mean[1], c->mean[2], c->stdv[0], c->stdv[1],
+                         c->stdv[2], (float4*)pl.in4);
+    else
+      hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
+                         (const float*)images, np, H * W, c->mean[0], c->mean[1],
+                         c->mean[2], c->stdv[0], c->stdv[1], c->stdv[2],
+                         (float4*)pl.in4);
+    MILAN_CHECK_HIP(hipGetLastError());
+  }
+
+  auto pool = [&](const float* tap, int level, int C, int col_off) -> int {
+    const int P = pl.lv.h[level] * pl.lv.w[level];
+    hipLaunchKernelGGL(masked_pool_kernel, dim3(n, (C + 63) / 64), dim3(256), 0,
+                       s, tap, P, C, level, pl.lv, pl.list_idx, pl.list_w,
+                       pl.list_n, features, F, col_off);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+
+  // 3. stem: raw conv1 (tap 0), then bn1+relu+maxpool
+  int ho, wo;
+  {
+    GemmArgs g = conv_args(c->stem, pl.in4, n, H, W, pl.raw, EPI_BIAS, nullptr,
+                           c->zero, &ho, &wo);
+    MILAN_TRY(launch_gemm(g, s));
+    MILAN_TRY(pool(pl.raw, 0, wd, 0));
+    const long total = (long)n * pl.hp * pl.wp * (wd / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, s,
+                       (const float4*)pl.raw, n, pl.h1, pl.w1, wd / 4, pl.hp,
+                       pl.wp, (const float4*)c->bn1_scale,
+                       (const float4*)c->bn1_shift, (float4*)pl.x0);
+    MILAN_CHECK_HIP(hipGetLastError());
+  }
+
+  // 4. bottleneck stages; tap after each stage
+  float *x = pl.x0, *y = pl.x1;
+  int h = pl.hp, w = pl.wp, col = wd;
+  for (int li = 0; li < 4; ++li) {
+    for (const Bottleneck& b : c->blocks[li]) {
+      int h1, w1, h2, w2, h3, w3;
+      GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
+                              c->zero, &h1, &w1);
+      MILAN_TRY(launch_gemm(g1, s));
+      GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU,
+                              nullptr, c->zero, &h2, &w2);
+      MILAN_TRY(launch_gemm(g2, s));
+      const float* identity = x;
+      if (b.has_down) {
+        int hd, wdn;
+        GemmArgs gd = conv_args(b.down, x, n, h, w, pl.ds, EPI_BIAS, nullptr,
+                                c->zero, &hd, &wdn);
+        MILAN_TRY(launch_gemm(gd, s));
+        identity = pl.ds;
+      }
+      GemmArgs g3 = conv_args(b.c3, pl.t2, n, h2, w2, y, EPI_BIAS_RES_RELU,
+                              identity, c->zero, &h3, &w3);
+      MILAN_TRY(launch_gemm(g3, s));
+      float* tmp = x; x = y; y = tmp;
+      h = h3; w = w3;
+    }
+    const int C = wd * 4 << li;
+    MILAN_REQUIRE(h == pl.lv.h[li + 1] && w == pl.lv.w[li + 1], MILAN_ERR_SHAPE,
+                  "internal: stage %d geometry mismatch", li + 1);
+    MILAN_TRY(pool(x, li + 1, C, col));
+    col += C;
+  }
+  return 0;
+}
+
+}  // namespace milan

@@ -1,0 +1,453 @@
+"""ctypes binding of libmilan_hip.so (the C ABI in include/milan_hip.h).
+
+This is the only place the Python mirror touches native code.  There is NO
+fallback: if the library cannot be loaded, or no HIP device is present,
+everything that computes raises `HipUnavailableError` -- the product path
+never routes through torch ops or the CPU oracle.
+
+Tensors cross the boundary as raw device pointers (`tensor.data_ptr()`) on
+torch's current HIP stream; torch only owns memory here.
+"""
+import ctypes
+import os
+import pathlib
+from typing import Dict, Optional, Sequence
+
+import torch
+
+LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so'
+
+GREEDY, BEAM, RERANK = 0, 2, 3  # MILAN_GREEDY / MILAN_BEAM / MILAN_RERANK
+DTYPE_U8, DTYPE_F32 = 0, 1
+
+ERR_ARG, ERR_SHAPE, ERR_STATE, ERR_WORKSPACE, ERR_NO_LM = -1, -2, -3, -4, -5
+
+
+class HipUnavailableError(RuntimeError):
+    """libmilan_hip.so or a HIP device is missing."""
+
+
+class Dims(ctypes.Structure):
+    """struct milan_dims."""
+    _fields_ = [
+        ('trunk_width', ctypes.c_int32),
+        ('trunk_blocks', ctypes.c_int32 * 4),
+        ('feature_size', ctypes.c_int32),
+        ('hidden_size', ctypes.c_int32),
+        ('embedding_size', ctypes.c_int32),
+        ('attention_size', ctypes.c_int32),
+        ('vocab_size', ctypes.c_int32),
+        ('start_index', ctypes.c_int32),
+        ('stop_index', ctypes.c_int32),
+        ('pad_index', ctypes.c_int32),
+        ('has_lm', ctypes.c_int32),
+        ('lm_hidden_size', ctypes.c_int32),
+        ('lm_embedding_size', ctypes.c_int32),
+        ('lm_layers', ctypes.c_int32),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_SZ = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/milan_hip.h
+# declares (tests/test_abi.py checks the two against each other).
+SIGNATURES = {
+    'milan_abi_version': (_I, []),
+    'milan_last_error': (ctypes.c_char_p, []),
+    'milan_create': (_I, [ctypes.POINTER(_P), _I,
+                          ctypes.POINTER(Dims)]),
+    'milan_destroy': (None, [_P]),
+    'milan_set_weight':
+        (_I, [_P, ctypes.c_char_p, _P,
+              ctypes.POINTER(ctypes.c_int64), _I]),
+    'milan_finalize_weights': (_I, [_P, _P]),
+    'milan_workspace_bytes': (_SZ, [_P, _I, _I, _I, _I, _I]),
+    'milan_encode': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    'milan_init_state': (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    'milan_step':
+        (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _SZ,
+              _P]),
+    'milan_decode': (_I, [
+        _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P,
+        _SZ, _P
+    ]),
+    'milan_lm_score': (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    'milan_describe': (_I, [
+        _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P,
+        _P, _P, _P, _P, _P, _P, _SZ, _P
+    ]),
+    'milan_conv2d_nhwc':
+        (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[os.PathLike] = None) -> ctypes.CDLL:
+    """dlopen libmilan_hip.so and attach signatures.  Loud on failure."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = pathlib.Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise HipUnavailableError(
+            f'{p} not found: build it with `python -c "import __graft_entry__ '
+            'as g; g.build()"` (or `make -C neuron-descriptions_amd/csrc`). '
+            'There is no CPU fallback for the MILAN hot path.')
+    try:
+        lib = ctypes.CDLL(str(p))
+    except OSError as error:
+        raise HipUnavailableError(f'cannot load {p}: {error}') from error
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def require_device(device: torch.device) -> torch.device:
+    device = torch.device(device)
+    if device.type != 'cuda' or not torch.cuda.is_available():
+        raise HipUnavailableError(
+            'milan_amd computes only on an AMD GPU (torch device "cuda" under '
+            f'ROCm); got device={device}, cuda.is_available()='
+            f'{torch.cuda.is_available()}. There is no CPU fallback.')
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    return device
+
+
+def _check(code: int) -> None:
+    if code == 0:
+        return
+    msg = load_library().milan_last_error().decode(errors='replace')
+    if code in (ERR_ARG, ERR_SHAPE, ERR_NO_LM):
+        raise ValueError(msg)  # the reference raises ValueError for these
+    raise RuntimeError(f'libmilan_hip error {code}: {msg}')
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _dev(t: torch.Tensor, device: torch.device, dtype=None) -> torch.Tensor:
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+class Context:
+    """Owns one `milan_ctx` (packed weights on one GPU) plus a workspace."""
+
+    def __init__(self, dims: Dims, state_dict: Dict[str, torch.Tensor],
+                 device: torch.device):
+        self.lib = load_library()
+        self.device = require_device(device)
+        self.dims = dims
+        self._h = _P()
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_create(ctypes.byref(self._h), self.device.index,
+                                      ctypes.byref(dims)))
+            keep = []
+            for name, tensor in state_dict.items():
+                if not tensor.dtype.is_floating_point:
+                    continue  # e.g. num_batches_tracked
+                t = _dev(tensor.detach(), self.device, torch.float32)
+                keep.append(t)
+                shape = (ctypes.c_int64 * max(1, t.dim()))(*t.shape)
+                _check(
+                    self.lib.milan_set_weight(self._h, name.encode(),
+                                              t.data_ptr(), shape, t.dim()))
+            _check(
+                self.lib.milan_finalize_weights(self._h,
+                                                _stream(self.device)))
+            del keep
+        self._ws: Optional[torch.Tensor] = None
+
+    def close(self) -> None:
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.milan_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter teardown
+            pass
+
+    # -- workspace ---------------------------------------------------------
+    def workspace(self, neurons: int, k: int, image_size: int, beam: int,
+                  length: int) -> torch.Tensor:
+        need = int(
+            self.lib.milan_workspace_bytes(self._h, neurons, k, image_size,
+                                           beam, length))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None  # free before growing
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # -- operators ----------------------------------------------------------
+    def encode(self, images: torch.Tensor,
+               masks: Optional[torch.Tensor]) -> torch.Tensor:
+        """(M,3,H,W) [+ (M,1,H,W)] -> (M,F).  uint8 or float inputs."""
+        m, ch, h, w = images.shape
+        if ch != 3:
+            raise ValueError(f'images must have 3 channels, got {ch}')
+        idt = DTYPE_U8 if images.dtype == torch.uint8 else DTYPE_F32
+        images = _dev(images, self.device,
+                      None if idt == DTYPE_U8 else torch.float32)
+        mdt = DTYPE_U8
+        if masks is not None:
+            if masks.shape != (m, 1, h, w):
+                raise ValueError(
+                    f'masks shape {tuple(masks.shape)} != {(m, 1, h, w)}')
+            mdt = DTYPE_U8 if masks.dtype == torch.uint8 else DTYPE_F32
+            masks = _dev(masks, self.device,
+                         None if mdt == DTYPE_U8 else torch.float32)
+        out = torch.empty(m,
+                          self.dims.feature_size,
+                          dtype=torch.float32,
+                          device=self.device)
+        ws = self.workspace((m + 0) or 1, 1, max(h, w), 1, 1)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_encode(self._h, images.data_ptr(), idt,
+                                      _ptr(masks), mdt, m, h, w,
+                                      out.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), _stream(self.device)))
+        return out
+
+    def init_state(self, features: torch.Tensor):
+        n, k, _ = features.shape
+        features = _dev(features, self.device, torch.float32)
+        h = torch.empty(n, self.dims.hidden_size, device=self.device)
+        c = torch.empty_like(h)
+        ws = self.workspace(n, k, 0, 1, 1)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_init_state(self._h, features.data_ptr(), n, k,
+                                          h.data_ptr(), c.data_ptr(),
+                                          ws.data_ptr(), ws.numel(),
+                                          _stream(self.device)))
+        return h, c
+
+    def step(self, features, tokens, h, c, h_lm, c_lm, temperature):
+        rows, k, _ = features.shape
+        features = _dev(features, self.device, torch.float32)
+        tokens = _dev(tokens, self.device, torch.long)
+        h = _dev(h, self.device, torch.float32)
+        c = _dev(c, self.device, torch.float32)
+        if h_lm is not None:
+            h_lm = _dev(h_lm, self.device, torch.float32).clone()
+            c_lm = _dev(c_lm, self.device, torch.float32).clone()
+        pred = torch.empty(rows, self.dims.vocab_size, device=self.device)
+        att = torch.empty(rows, k, device=self.device)
+        h2, c2 = torch.empty_like(h), torch.empty_like(c)
+        ws = self.workspace(rows, k, 0, 1, 1)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_step(self._h, features.data_ptr(), rows, k,
+                                    tokens.data_ptr(), h.data_ptr(),
+                                    c.data_ptr(), _ptr(h_lm), _ptr(c_lm),
+                                    float(temperature), pred.data_ptr(),
+                                    att.data_ptr(), h2.data_ptr(),
+                                    c2.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    _stream(self.device)))
+        return pred, att, h2, c2, h_lm, c_lm
+
+    def _alloc_outputs(self, n, k, strategy, length, beam, want_full):
+        dev = self.device
+        out = dict(tokens=torch.empty(n, length, dtype=torch.long, device=dev),
+                   scores=torch.empty(n, device=dev),
+                   predictions=None,
+                   attentions=None,
+                   beam_tokens=None,
+                   beam_scores=None,
+                   out_len=None)
+        if strategy == GREEDY:
+            if want_full:
+                out['predictions'] = torch.empty(n,
+                                                 length,
+                                                 self.dims.vocab_size,
+                                                 device=dev)
+                out['attentions'] = torch.empty(n, length, k, device=dev)
+        else:
+            out['beam_tokens'] = torch.empty(n,
+                                             beam,
+                                             length,
+                                             dtype=torch.long,
+                                             device=dev)
+            out['beam_scores'] = torch.empty(n, beam, device=dev)
+        return out
+
+    def decode(self,
+               features: torch.Tensor,
+               strategy: int,
+               length: int,
+               beam: int,
+               mi: bool,
+               temperature: float,
+               group_size: int = 0,
+               want_full: bool = True):
+        n, k, _ = features.shape
+        features = _dev(features, self.device, torch.float32)
+        out = self._alloc_outputs(n, k, strategy, length, beam, want_full)
+        groups = (n + group_size - 1) // group_size if group_size > 0 else 1
+        out['out_len'] = torch.full((groups,),
+                                    length,
+                                    dtype=torch.int32,
+                                    device=self.device)
+        ws = self.workspace(n, k, 0, beam, length)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_decode(
+                    self._h, features.data_ptr(), n, k, strategy, length, beam,
+                    int(bool(mi)), float(temperature), group_size,
+                    out['tokens'].data_ptr(), out['scores'].data_ptr(),
+                    _ptr(out['predictions']), _ptr(out['attentions']),
+                    _ptr(out['beam_tokens']), _ptr(out['beam_scores']),
+                    out['out_len'].data_ptr(), ws.data_ptr(), ws.numel(),
+                    _stream(self.device)))
+        return out
+
+    def lm_score(self, seqs: torch.Tensor) -> torch.Tensor:
+        rows, length = seqs.shape
+        seqs = _dev(seqs, self.device, torch.long)
+        out = torch.empty(rows, device=self.device)
+        ws = self.workspace(rows, 1, 0, 1, 1)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_lm_score(self._h, seqs.data_ptr(), rows, length,
+                                        None, out.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), _stream(self.device)))
+        return out
+
+    def describe(self,
+                 images: torch.Tensor,
+                 masks: Optional[torch.Tensor],
+                 strategy: int,
+                 length: int,
+                 beam: int,
+                 mi: bool,
+                 temperature: float,
+                 group_size: int = 0,
+                 want_full: bool = False,
+                 want_features: bool = False):
+        """Fused hot path on (n,k,3,H,W) images (+ (n,k,1,H,W) masks)."""
+        n, k, ch, h, w = images.shape
+        idt = DTYPE_U8 if images.dtype == torch.uint8 else DTYPE_F32
+        images = _dev(images, self.device,
+                      None if idt == DTYPE_U8 else torch.float32)
+        mdt = DTYPE_U8
+        if masks is not None:
+            mdt = DTYPE_U8 if masks.dtype == torch.uint8 else DTYPE_F32
+            masks = _dev(masks, self.device,
+                         None if mdt == DTYPE_U8 else torch.float32)
+        out = self._alloc_outputs(n, k, strategy, length, beam, want_full)
+        groups = (n + group_size - 1) // group_size if group_size > 0 else 1
+        out['out_len'] = torch.full((groups,),
+                                    length,
+                                    dtype=torch.int32,
+                                    device=self.device)
+        feats = None
+        if want_features:
+            feats = torch.empty(n,
+                                k,
+                                self.dims.feature_size,
+                                device=self.device)
+        out['features'] = feats
+        ws = self.workspace(n, k, max(h, w), beam, length)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_describe(
+                    self._h, images.data_ptr(), idt, _ptr(masks), mdt, n, k, h,
+                    w, strategy, length, beam, int(bool(mi)),
+                    float(temperature), group_size, _ptr(feats),
+                    out['tokens'].data_ptr(), out['scores'].data_ptr(),
+                    _ptr(out['predictions']), _ptr(out['attentions']),
+                    _ptr(out['beam_tokens']), _ptr(out['beam_scores']),
+                    out['out_len'].data_ptr(), ws.data_ptr(), ws.numel(),
+                    _stream(self.device)))
+        return out
+
+
+def conv2d_nhwc(x: torch.Tensor,
+                weight: torch.Tensor,
+                bias: Optional[torch.Tensor] = None,
+                stride: int = 1,
+                padding: int = 0,
+                relu: bool = False,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Test hook for the implicit-GEMM kernel (milan_conv2d_nhwc)."""
+    lib = load_library()
+    device = require_device(x.device)
+    n, h, w, cin = x.shape
+    cout, cin_w, kh, kw = weight.shape
+    assert cin_w == cin
+    ho = (h + 2 * padding - kh) // stride + 1
+    wo = (w + 2 * padding - kw) // stride + 1
+    y = torch.empty(n, ho, wo, cout, device=device)
+    x, weight = x.contiguous(), weight.contiguous()
+    with torch.cuda.device(device):
+        _check(
+            lib.milan_conv2d_nhwc(x.data_ptr(), n, h, w, cin,
+                                  weight.data_ptr(), _ptr(bias), cout, kh, kw,
+                                  stride, padding, int(relu), _ptr(residual),
+                                  y.data_ptr(), _stream(device)))
+    return y
+
+
+def make_dims(state_dict: Dict[str, torch.Tensor],
+              n_vocab_tokens: int,
+              blocks: Sequence[int] = (3, 4, 23, 3)) -> Dims:
+    """Derive `milan_dims` from a reference state dict + vocabulary size."""
+    d = Dims()
+    sd = state_dict
+    enc = 'encoder.encoder.model.conv1.weight'
+    width = sd[enc].shape[0] if enc in sd else None
+    if 'lstm.weight_hh' in sd:
+        hidden = sd['lstm.weight_hh'].shape[1]
+        emb = sd['embedding.weight'].shape[1]
+        feat = sd['lstm.weight_ih'].shape[1] - emb
+        att = sd['attend.query_to_hidden.weight'].shape[0]
+        vocab = sd['output.1.weight'].shape[0]
+    else:
+        hidden, emb, att, vocab = 4, 4, 4, n_vocab_tokens + 4
+        feat = 61 * width
+    if width is None:
+        if feat % 61:
+            raise ValueError(f'feature size {feat} is not a pyramid (61*w)')
+        width = feat // 61
+    if vocab != n_vocab_tokens + 4:
+        raise ValueError(
+            f'output layer has {vocab} classes but the indexer has '
+            f'{n_vocab_tokens} tokens + 4 specials')
+    d.trunk_width = width
+    for i, b in enumerate(blocks):
+        d.trunk_blocks[i] = b
+    d.feature_size, d.hidden_size, d.embedding_size = feat, hidden, emb
+    d.attention_size, d.vocab_size = att, vocab
+    d.start_index = n_vocab_tokens
+    d.stop_index = n_vocab_tokens + 1
+    d.pad_index = n_vocab_tokens + 2
+    d.has_lm = int('lm.lstm.weight_hh_l0' in sd)
+    if d.has_lm:
+        d.lm_hidden_size = sd['lm.lstm.weight_hh_l0'].shape[1]
+        d.lm_embedding_size = sd['lm.embedding.weight'].shape[1]
+        layers = 0
+        while f'lm.lstm.weight_hh_l{layers}' in sd:
+            layers += 1
+        d.lm_layers = layers
+    return d
