@@ -329,7 +329,7 @@ def test_describe_end_to_end_matches_oracle(dev, strategy):
     images, masks = synthetic.exemplars(n, k=k, size=size, seed=5, zero_every=7)
     feats = O.encode(O.byte_to_float(images), masks.float(), sd,
                      blocks=synthetic.RESNET_BLOCKS['resnet50'])
-    want = O.forward(feats, sd, nv, strategy, length=10, beam_size=4)
+    want = O.forward(feats, sd, nv, strategy, length=10, beam_size=4, mi=False)
     out = ctx.describe(images,
                        masks,
                        hip.GREEDY if strategy == 'greedy' else hip.RERANK,
