@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""MILAN hot-path benchmark (driver contract: one JSON line on rank 0).
+
+Workload (BASELINE.json `metric`): synthetic
+4096 neurons x k=15 exemplars x 3x224x224 uint8 + {0,1} masks, ResNet-101
+pyramid encoder -> attention-LSTM beam search (beam 50, length 15) -> LM (PMI)
+rerank (lambda 0.2), seeded synthetic weights, V = 5004.  A "step" is one pass
+of the hot path (milan_describe through the C ABI) over one chunk of
+`--chunk` neurons whose uint8 exemplars are already resident in HBM; the
+default 16 steps x 256 neurons = the 4096-neuron workload.  Rank r of N
+processes its own neurons (no data-path collective; weights broadcast from
+rank 0 over RCCL, results gathered at the end) => "scaling": "weak".
+
+    python bench.py                      # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+        --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+REPO = pathlib.Path(__file__).resolve().parent
+for p in (REPO, REPO / 'neuron-descriptions_amd'):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import torch  # noqa: E402
+
+from milan_amd import hip, sharding, synthetic  # noqa: E402
+
+# algorithmic GFLOP per neuron-description.
+GFLOP_ENCODER = 233.97
+GFLOP_DECODER = {1: 0.494, 16: 6.456, 50: 19.970}
+GFLOP_LM = {16: 3.057, 50: 9.552}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, f32-in MFMA
+
+
+def algorithmic_gflop(beam: int, rerank: bool, k: int = 15, f: int = 3904,
+                      h: int = 512, a: int = 512, e: int = 128,
+                      v: int = 5004, t: int = 15) -> float:
+    """SURVEY.md 8(d) formulas, evaluated for arbitrary beam."""
+    rows = 1 + (t - 1) * beam
+    dec = 2 * (k * f * a + 2 * f * h + rows *
+               (h * a + k * a + h * f + k * f + (e + f + h) * 4 * h + h * v))
+    lm = 2 * beam * 16 * ((e + h) * 4 * h + 2 * h * 4 * h + h * v) if rerank \
+        else 0
+    return GFLOP_ENCODER + (dec + lm) / 1e9
+
+
+def cpu_baseline(sd, nv, beam, length, temperature, sample):
+    """Time the oracle (kind 'port') on the host cores on a bounded sample."""
+    from oracle import milan_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    images, masks = synthetic.exemplars(sample, k=15, size=224, seed=1)
+    with torch.no_grad():
+        # warm-up: one image through the trunk
+        O.encode(O.byte_to_float(images[:1, :1]), masks[:1, :1].float(), sd)
+        t0 = time.perf_counter()
+        feats = O.encode(O.byte_to_float(images), masks.float(), sd, chunk=15)
+        t_enc = time.perf_counter() - t0
+        O.forward(feats, sd, nv, 'rerank', length, beam, temperature)
+        t_all = time.perf_counter() - t0
+    return {
+        'value': sample / t_all,
+        'unit': 'neuron-descriptions/sec',
+        'cores': torch.get_num_threads(),
+        'kind': 'port',
+        'sample': (f'{sample} neurons x 15 exemplars x 224^2, same pipeline '
+                   f'(beam {beam} + rerank), torch-CPU fp32 oracle; encoder '
+                   f'{t_enc:.1f}s of {t_all:.1f}s'),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--chunk', type=int, default=256,
+                    help='neurons per step (per GPU)')
+    ap.add_argument('--beam', type=int, default=50)
+    ap.add_argument('--length', type=int, default=15)
+    ap.add_argument('--temperature', type=float, default=0.2)
+    ap.add_argument('--vocab', type=int, default=5000,
+                    help='vocabulary tokens (V = vocab + 4 specials)')
+    ap.add_argument('--strategy', default='rerank',
+                    choices=['greedy', 'beam', 'rerank'])
+    ap.add_argument('--cpu-sample', type=int, default=8,
+                    help='neurons for the CPU baseline leg (0 = skip)')
+    ap.add_argument('--no-profile', action='store_true',
+                    help='do not bracket GEMM launches with HIP events')
+    args = ap.parse_args()
+
+    rank, world, local = sharding.init_from_env(args.gpus)
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    nv = args.vocab
+    blocks = synthetic.RESNET_BLOCKS['resnet101']
+    # Rank 0 builds the (synthetic) checkpoint; the others receive it by RCCL
+    # broadcast over xGMI, as a real deployment would distribute milan-base.pth.
+    sd = synthetic.milan_state_dict(nv + 4, 'resnet101', seed=0) \
+        if rank == 0 else None
+    sd_dev = sharding.broadcast_state_dict(sd, device, src=0)
+    ctx = hip.Context(hip.make_dims(sd_dev, nv, blocks=blocks), sd_dev, device)
+    del sd_dev
+
+    strategy = {'greedy': hip.GREEDY, 'beam': hip.BEAM,
+                'rerank': hip.RERANK}[args.strategy]
+    beam = 1 if strategy == hip.GREEDY else args.beam
+    n_steps_data = max(1, args.steps)
+    # uint8 exemplars resident in HBM before the timed region starts
+    images, masks = synthetic.exemplars(args.chunk * n_steps_data, k=15,
+                                        size=224, seed=1 + rank,
+                                        device=str(device))
+    torch.cuda.synchronize()
+
+    def step(i):
+        lo = (i % n_steps_data) * args.chunk
+        return ctx.describe(images[lo:lo + args.chunk],
+                            masks[lo:lo + args.chunk], strategy, args.length,
+                            beam, False, args.temperature, group_size=16)
+
+    for i in range(args.warmup):
+        step(i)
+    sharding.barrier()
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        hip.profile_enable(True)
+    t0 = time.perf_counter()
+    outs = [step(i) for i in range(args.steps)]
+    torch.cuda.synchronize()
+    sharding.barrier()
+    elapsed = time.perf_counter() - t0
+    gemm_ms = gemm_flops = gemm_launches = None
+    if not args.no_profile:
+        gemm_ms, gemm_flops, gemm_launches = hip.profile_read()
+        hip.profile_enable(False)
+    elapsed = sharding.max_over_ranks(elapsed, device)
+
+    # final gather of the top-1 token ids + scores (section 8e); not timed
+    tokens = torch.cat([o['tokens'] for o in outs])
+    scores = torch.cat([o['scores'] for o in outs])
+    all_tokens, all_scores = sharding.gather_results(tokens, scores, dst=0)
+
+    if rank != 0:
+        sharding.finalize()
+        return
+    neurons = args.steps * args.chunk * world
+    value = neurons / elapsed
+    result = {
+        'metric': 'neuron-descriptions/sec (whole node), 4096 neurons x k=15 '
+                  'exemplars',
+        'value': value,
+        'unit': 'neuron-descriptions/sec',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': (f'{args.steps * args.chunk} neurons/GPU x k=15 x '
+                         f'3x224x224 u8 + masks; resnet101 pyramid encoder -> '
+                         f'attention-LSTM {args.strategy} (beam {beam}, length '
+                         f'{args.length}, lambda {args.temperature}); V='
+                         f'{nv + 4}; synthetic seeded weights'),
+            'neurons_per_step': args.chunk,
+            'neurons_total': neurons,
+            'parallelism': f'neuron-sharded x{world}',
+            'gathered_tokens': list(all_tokens.shape),
+        },
+    }
+    if gemm_ms:
+        g_alg = algorithmic_gflop(beam, strategy == hip.RERANK)
+        per_launch_flop = g_alg * 1e9 * args.steps * args.chunk / gemm_launches
+        avg_ms = gemm_ms / gemm_launches
+        achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
+        result['roofline'] = {
+            'bound': 'mfma',
+            'kernel': 'igemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
+            'achieved': achieved,
+            'peak': PEAK_F32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s',
+            'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+            'traffic': None,
+            'launches': gemm_launches,
+            'avg_launch_ms': avg_ms,
+            'algorithmic_gflop_per_neuron': g_alg,
+            'counted_gflop_per_neuron':
+                gemm_flops / 1e9 / (args.steps * args.chunk),
+            'gemm_time_frac_of_step': gemm_ms * 1e-3 / elapsed,
+        }
+    else:
+        result['roofline'] = None
+    if world == 1 and args.cpu_sample > 0:
+        sd = synthetic.milan_state_dict(nv + 4, 'resnet101', seed=0)
+        result['cpu_baseline'] = cpu_baseline(sd, nv, beam, args.length,
+                                              args.temperature,
+                                              args.cpu_sample)
+    else:
+        result['cpu_baseline'] = None
+    print(json.dumps(result), flush=True)
+    sharding.finalize()
+
+
+if __name__ == '__main__':
+    main()

@@ -165,6 +165,15 @@ int milan_describe(milan_ctx* ctx, const void* images, int image_dtype,
                    int32_t* out_len, void* workspace, size_t workspace_bytes,
                    milan_stream stream);
 
+/* Measurement hook (bench.py's roofline leg): while enabled, every launch of
+ * the implicit-GEMM MFMA kernel is bracketed by HIP events on its launch
+ * stream.  milan_profile_read synchronises the device and returns the summed
+ * kernel time (ms), the algorithmic FLOPs (2*M*N*K, un-padded K) and the launch
+ * count since milan_profile_enable(1).  Process-wide; not for production. */
+int milan_profile_enable(int enable);
+int milan_profile_read(double* gemm_ms, double* gemm_flops,
+                       long long* gemm_launches);
+
 /* Building block exposed for kernel-level parity tests: one NHWC fp32
  * convolution through the same implicit-GEMM MFMA kernel the trunk uses
  * (counterpart of torch.nn.functional.conv2d as torchvision's ResNet calls it).

@@ -227,6 +227,13 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
   return r;
 }
 
+int milan_profile_enable(int enable) { return gemm_profile_enable(enable); }
+
+int milan_profile_read(double* gemm_ms, double* gemm_flops,
+                       long long* gemm_launches) {
+  return gemm_profile_read(gemm_ms, gemm_flops, gemm_launches);
+}
+
 int milan_describe(milan_ctx* c, const void* images, int image_dtype,
                    const void* masks, int mask_dtype, int n, int k, int height,
                    int width, int strategy, int length, int beam_size, int mi,

@@ -64,9 +64,12 @@ struct GemmArgs {
   long a_img_stride;  // floats between consecutive images
   int epilogue;
   const float* zero;  // >= 64 B of zeros (device)
+  int flop_k;         // algorithmic K for FLOP accounting (0 = K)
 };
 
 int launch_gemm(const GemmArgs& g, hipStream_t s);
+int gemm_profile_enable(int enable);
+int gemm_profile_read(double* ms, double* flops, long long* launches);
 
 inline GemmArgs linear_args(const float* A, long lda, const float* W,
                             const float* bias, float* C, int ldc, int M, int N,
@@ -88,6 +91,7 @@ struct ConvW {
   float* w = nullptr;     // [Cout][Kp]
   float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
   int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;
+  int cin_real = 0;  // channels before padding to a multiple of 4
 };
 struct Bottleneck {
   ConvW c1, c2, c3, down;

@@ -81,6 +81,7 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
   }
   out->cout = (int)w->shape[0];
   out->cin = ((int)w->shape[1] + 3) / 4 * 4;
+  out->cin_real = (int)w->shape[1];
   out->kh = (int)w->shape[2];
   out->kw = (int)w->shape[3];
   out->stride = stride;
@@ -403,6 +404,7 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
   g.a_pix_stride = cw.cin;
   g.a_img_stride = (long)H * W * cw.cin;
   g.epilogue = epi; g.zero = zero;
+  g.flop_k = cw.kh * cw.kw * cw.cin_real;
   return g;
 }
 

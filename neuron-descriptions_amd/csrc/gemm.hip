@@ -25,6 +25,8 @@
 //   same 4 MiB L2.
 #include "common.h"
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 namespace milan {
 
@@ -257,13 +259,39 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   return 0;
 }
 
-int launch_gemm(const GemmArgs& g, hipStream_t s) {
-  MILAN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, MILAN_ERR_SHAPE,
-                "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
-  MILAN_REQUIRE(g.Cin % 4 == 0 && g.a_pix_stride % 4 == 0 &&
-                    g.a_img_stride % 4 == 0 && g.Kp % 32 == 0,
-                MILAN_ERR_SHAPE,
-                "gemm: Cin=%d / strides must be multiples of 4 floats", g.Cin);
+// ---- live kernel timing (bench.py's roofline leg) ---------------------------
+// HIP events are recorded on the launch stream right before/after each GEMM
+// launch while profiling is enabled; durations are read back after a sync.
+struct GemmProfiler {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t used = 0;
+  double flops = 0.0;
+};
+static GemmProfiler g_prof;
+
+int gemm_profile_enable(int enable) {
+  g_prof.on = enable != 0;
+  g_prof.used = 0;
+  g_prof.flops = 0.0;
+  return 0;
+}
+
+int gemm_profile_read(double* ms, double* flops, long long* launches) {
+  MILAN_CHECK_HIP(hipDeviceSynchronize());
+  double total = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    float t = 0.f;
+    MILAN_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
+    total += t;
+  }
+  if (ms) *ms = total;
+  if (flops) *flops = g_prof.flops;
+  if (launches) *launches = (long long)g_prof.used;
+  return 0;
+}
+
+static int launch_gemm_impl(const GemmArgs& g, hipStream_t s) {
   const bool cin32 = (g.Cin % 32 == 0);
   if (g.N <= 64) {
     return cin32 ? launch_cfg<256, 64, 64, 64, true>(g, s)
@@ -271,6 +299,28 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
   }
   return cin32 ? launch_cfg<128, 128, 64, 64, true>(g, s)
                : launch_cfg<128, 128, 64, 64, false>(g, s);
+}
+
+int launch_gemm(const GemmArgs& g, hipStream_t s) {
+  MILAN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, MILAN_ERR_SHAPE,
+                "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
+  MILAN_REQUIRE(g.Cin % 4 == 0 && g.a_pix_stride % 4 == 0 &&
+                    g.a_img_stride % 4 == 0 && g.Kp % 32 == 0,
+                MILAN_ERR_SHAPE,
+                "gemm: Cin=%d / strides must be multiples of 4 floats", g.Cin);
+  if (!g_prof.on) return launch_gemm_impl(g, s);
+  if (g_prof.used == g_prof.ev.size()) {
+    hipEvent_t a, b;
+    MILAN_CHECK_HIP(hipEventCreate(&a));
+    MILAN_CHECK_HIP(hipEventCreate(&b));
+    g_prof.ev.emplace_back(a, b);
+  }
+  auto& e = g_prof.ev[g_prof.used++];
+  MILAN_CHECK_HIP(hipEventRecord(e.first, s));
+  const int r = launch_gemm_impl(g, s);
+  MILAN_CHECK_HIP(hipEventRecord(e.second, s));
+  g_prof.flops += 2.0 * (double)g.M * (double)g.N * (double)(g.flop_k > 0 ? g.flop_k : g.K);
+  return r;
 }
 
 }  // namespace milan

@@ -79,6 +79,12 @@ SIGNATURES = {
         _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P,
         _P, _P, _P, _P, _P, _P, _SZ, _P
     ]),
+    'milan_profile_enable': (_I, [_I]),
+    'milan_profile_read': (_I, [
+        ctypes.POINTER(ctypes.c_double),
+        ctypes.POINTER(ctypes.c_double),
+        ctypes.POINTER(ctypes.c_longlong)
+    ]),
     'milan_conv2d_nhwc':
         (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
 }
@@ -381,6 +387,18 @@ class Context:
                     out['out_len'].data_ptr(), ws.data_ptr(), ws.numel(),
                     _stream(self.device)))
         return out
+
+
+def profile_enable(enable: bool) -> None:
+    _check(load_library().milan_profile_enable(int(enable)))
+
+
+def profile_read():
+    """-> (gemm_ms, gemm_flops, gemm_launches) since profile_enable(True)."""
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+    _check(load_library().milan_profile_read(ctypes.byref(ms), ctypes.byref(fl),
+                                             ctypes.byref(n)))
+    return ms.value, fl.value, n.value
 
 
 def conv2d_nhwc(x: torch.Tensor,

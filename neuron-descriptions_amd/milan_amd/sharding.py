@@ -1,0 +1,161 @@
+"""Neuron sharding across the GPUs of one node.
+
+The path is embarrassingly parallel over neurons: a description depends only
+on that neuron's k exemplars and the read-only weights.  One process per GPU
+(`torch.distributed`, backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU
+for tests).  Exactly two collectives exist, neither on the data path:
+  * one broadcast of the checkpoint tensors from rank 0 at start-up;
+  * one gather of top-1 token ids + scores at the end.
+The reference has no distributed code at all; this is
+new, not a translation.
+"""
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def partition(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of the neuron index owned by `rank`.
+
+    Block size ceil(n / world) (last ranks may get fewer / none); keeps the
+    reference's CSV order when shards are concatenated rank by rank.
+    """
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f'bad rank/world: {rank}/{world}')
+    per = -(-n // world)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def init_from_env(expected_world: Optional[int] = None,
+                  backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).
+
+    Returns (rank, world, local_rank).  Single-process when WORLD_SIZE is
+    unset or 1.
+    """
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if expected_world is not None and expected_world != world:
+        raise RuntimeError(
+            f'--gpus {expected_world} but WORLD_SIZE={world}; launch with '
+            'python -m torch.distributed.run --nproc-per-node N ...')
+    if world > 1 and not is_distributed():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def barrier() -> None:
+    if is_distributed():
+        dist.barrier()
+
+
+def finalize() -> None:
+    if is_distributed():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    if not is_distributed():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]],
+                         device: torch.device,
+                         src: int = 0) -> Dict[str, torch.Tensor]:
+    """Give every rank the checkpoint that only `src` has loaded.
+
+    Metadata (names, shapes, dtypes) goes as one object broadcast; the float
+    tensors are packed into ONE flat buffer so the payload is a single large
+    RCCL broadcast (xGMI is point-to-point; one 280 MB message uses the links
+    far better than ~800 small ones).  Integer tensors (num_batches_tracked)
+    travel in a second, tiny buffer.
+    """
+    if not is_distributed():
+        assert sd is not None
+        return {k: v.to(device) for k, v in sd.items()}
+    rank = dist.get_rank()
+    meta: List = [None]
+    if rank == src:
+        assert sd is not None
+        meta[0] = [(k, tuple(v.shape), str(v.dtype).replace('torch.', ''))
+                   for k, v in sd.items()]
+    dist.broadcast_object_list(meta, src=src)
+    entries = meta[0]
+    out: Dict[str, torch.Tensor] = {}
+    for is_float in (True, False):
+        names = [(k, s, d) for k, s, d in entries
+                 if getattr(torch, d).is_floating_point == is_float]
+        if not names:
+            continue
+        dtype = torch.float32 if is_float else torch.int64
+        total = sum(int(torch.Size(s).numel()) for _, s, _ in names)
+        flat = torch.empty(total, dtype=dtype, device=device)
+        if rank == src:
+            off = 0
+            for k, s, _ in names:
+                n = int(torch.Size(s).numel())
+                flat[off:off + n] = sd[k].reshape(-1).to(device=device,
+                                                         dtype=dtype)
+                off += n
+        dist.broadcast(flat, src=src)
+        off = 0
+        for k, s, d in names:
+            n = int(torch.Size(s).numel())
+            out[k] = flat[off:off + n].view(s).to(getattr(torch, d))
+            off += n
+    # preserve the checkpoint's key order
+    return {k: out[k] for k, _, _ in entries}
+
+
+def gather_results(tokens: torch.Tensor,
+                   scores: torch.Tensor,
+                   dst: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Concatenate per-rank (n_r, T) tokens / (n_r,) scores on `dst` in rank
+    order.  Ranks may hold different n_r (ragged last shard)."""
+    if not is_distributed():
+        return tokens, scores
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([tokens.shape[0]], dtype=torch.int64, device=tokens.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts_i = [int(c.item()) for c in counts]
+    cap = max(counts_i) if counts_i else 0
+    t_len = tokens.shape[1]
+    pad_t = tokens.new_zeros(cap, t_len)
+    pad_s = scores.new_zeros(cap)
+    pad_t[:tokens.shape[0]] = tokens
+    pad_s[:scores.shape[0]] = scores
+    if rank == dst:
+        bufs_t = [torch.empty_like(pad_t) for _ in range(world)]
+        bufs_s = [torch.empty_like(pad_s) for _ in range(world)]
+        dist.gather(pad_t, bufs_t, dst=dst)
+        dist.gather(pad_s, bufs_s, dst=dst)
+        return (torch.cat([b[:c] for b, c in zip(bufs_t, counts_i)]),
+                torch.cat([b[:c] for b, c in zip(bufs_s, counts_i)]))
+    dist.gather(pad_t, None, dst=dst)
+    dist.gather(pad_s, None, dst=dst)
+    return tokens, scores
+
+
+def shard_sequence(items: Sequence, world: int, rank: int) -> Sequence:
+    lo, hi = partition(len(items), world, rank)
+    return items[lo:hi]

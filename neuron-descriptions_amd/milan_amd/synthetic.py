@@ -220,14 +220,20 @@ def exemplars(n_neurons: int,
     ww = torch.randint(lo, hi + 1, (m,), generator=gm)
     y0 = (torch.rand(m, generator=gm) * (size - hh + 1)).long()
     x0 = (torch.rand(m, generator=gm) * (size - ww + 1)).long()
-    ys = torch.arange(size).view(1, size, 1)
-    xs = torch.arange(size).view(1, 1, size)
-    inside = ((ys >= y0.view(-1, 1, 1)) & (ys < (y0 + hh).view(-1, 1, 1)) &
-              (xs >= x0.view(-1, 1, 1)) & (xs < (x0 + ww).view(-1, 1, 1)))
+    # rectangle parameters come from the CPU generator (same on every box);
+    # the rasterisation happens on the target device, in bounded slabs.
+    hh, ww, y0, x0 = (t.to(device).view(-1, 1, 1) for t in (hh, ww, y0, x0))
+    ys = torch.arange(size, device=device).view(1, size, 1)
+    xs = torch.arange(size, device=device).view(1, 1, size)
+    masks = torch.empty(m, size, size, dtype=torch.uint8, device=device)
+    slab = 4096
+    for lo in range(0, m, slab):
+        sl = slice(lo, lo + slab)
+        masks[sl] = ((ys >= y0[sl]) & (ys < y0[sl] + hh[sl]) & (xs >= x0[sl]) &
+                     (xs < x0[sl] + ww[sl])).to(torch.uint8)
     if zero_every:
-        inside[zero_every - 1::zero_every] = False
-    masks = inside.to(torch.uint8).view(n_neurons, k, 1, size, size)
-    return images, masks.to(device)
+        masks[zero_every - 1::zero_every] = 0
+    return images, masks.view(n_neurons, k, 1, size, size)
 
 
 def describe(sd: Dict[str, torch.Tensor]) -> Sequence[str]:
