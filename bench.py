@@ -53,12 +53,18 @@ def algorithmic_gflop(beam: int, rerank: bool, k: int = 15, f: int = 3904,
 def cpu_baseline(sd, nv, beam, length, temperature, sample):
     """Time the oracle (kind 'port') on the host cores on a bounded sample."""
     from oracle import milan_oracle as O
-    cores = os.cpu_count() or 1
+    # torch's CPU conv collapses when oversubscribed on many-core hosts (256
+    # threads: 88 s/neuron measured in round 1); cap the pool and say so.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     images, masks = synthetic.exemplars(sample, k=15, size=224, seed=1)
     with torch.no_grad():
-        # warm-up: one image through the trunk
-        O.encode(O.byte_to_float(images[:1, :1]), masks[:1, :1].float(), sd)
+        # warm-up + calibration: ONE neuron, then size the sample to ~20 s
+        t0 = time.perf_counter()
+        O.encode(O.byte_to_float(images[:1]), masks[:1].float(), sd, chunk=15)
+        t_one = time.perf_counter() - t0
+        sample = max(1, min(sample, int(20.0 / max(t_one, 1e-3))))
+        images, masks = images[:sample], masks[:sample]
         t0 = time.perf_counter()
         feats = O.encode(O.byte_to_float(images), masks.float(), sd, chunk=15)
         t_enc = time.perf_counter() - t0
@@ -70,8 +76,9 @@ def cpu_baseline(sd, nv, beam, length, temperature, sample):
         'cores': torch.get_num_threads(),
         'kind': 'port',
         'sample': (f'{sample} neurons x 15 exemplars x 224^2, same pipeline '
-                   f'(beam {beam} + rerank), torch-CPU fp32 oracle; encoder '
-                   f'{t_enc:.1f}s of {t_all:.1f}s'),
+                   f'(beam {beam} + rerank), torch-CPU fp32 oracle on '
+                   f'{torch.get_num_threads()} threads of {os.cpu_count()} '
+                   f'cpus; encoder {t_enc:.1f}s of {t_all:.1f}s'),
     }
 
 
