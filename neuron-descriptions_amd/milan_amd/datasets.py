@@ -1,0 +1,133 @@
+"""Input side: exemplar images + masks on disk -> tensors.
+
+On-disk contract (writer `src/exemplars/compute.py:217-218`, reader
+`src/milannotations/datasets.py:159-197`): `<root>/<layer>/images.npy` uint8
+(units, k, 3, H, W), `masks.npy` uint8 {0,1} (units, k, 1, H, W), optional
+`units.npy` int (units,).
+
+The reference inflates the whole dataset to float32 in host RAM (49 GB for 4k
+units).  Here the arrays are memory-mapped and stay uint8 until the GPU; the
+byte->float conversion (`x * float32(1/255)`) happens inside the encoder's
+input kernel.  `__getitem__` still hands out the reference's `TopImages`
+tuples (float tensors, images in [0,1]) so foreign code keeps working, and
+`slice_uint8` is the zero-copy fast path `Decoder.predict` uses.
+"""
+import pathlib
+from typing import Iterable, NamedTuple, Optional, Tuple, Union
+
+import numpy
+import torch
+from torch.utils import data
+
+
+class TopImages(NamedTuple):
+    """Top images for a unit (reference datasets.py:20-26)."""
+    layer: str
+    unit: int
+    images: torch.Tensor
+    masks: torch.Tensor
+
+
+class TopImagesDataset(data.Dataset):
+    """Top-activating images for individual units, memory-mapped uint8."""
+
+    def __init__(self,
+                 root: Union[str, pathlib.Path],
+                 name: Optional[str] = None,
+                 layers: Optional[Iterable[Union[str, int]]] = None,
+                 mmap: bool = True):
+        root = pathlib.Path(root)
+        if not root.is_dir():
+            raise FileNotFoundError(f'root directory not found: {root}')
+        if layers is None:
+            layers = [f.name for f in root.iterdir() if f.is_dir()]
+        if not layers:
+            raise ValueError('no layers given and root has no subdirectories')
+        self.root = root
+        self.name = name or f'{root.parent.name}/{root.name}'
+        self.layers = tuple(sorted(str(layer) for layer in layers))
+        self.images_by_layer, self.masks_by_layer, self.units_by_layer = {}, {}, {}
+        self._index = []  # (layer, position)
+        mode = 'r' if mmap else None
+        for layer in self.layers:
+            for fname in ('images.npy', 'masks.npy'):
+                if not (root / layer / fname).exists():
+                    raise FileNotFoundError(f'{layer} is missing {fname}')
+            images = numpy.load(root / layer / 'images.npy', mmap_mode=mode)
+            masks = numpy.load(root / layer / 'masks.npy', mmap_mode=mode)
+            for what, arr in (('images', images), ('masks', masks)):
+                if arr.ndim != 5:
+                    raise ValueError(f'expected 5D {what}, got {arr.ndim}D '
+                                     f'in layer {layer}')
+            if images.shape[:2] != masks.shape[:2]:
+                raise ValueError(f'layer {layer} masks/images have different '
+                                 f'# unit/images: {images.shape[:2]} vs. '
+                                 f'{masks.shape[:2]}')
+            if images.shape[3:] != masks.shape[3:]:
+                raise ValueError(f'layer {layer} masks/images have different '
+                                 f'height/width {images.shape[3:]} vs. '
+                                 f'{masks.shape[3:]}')
+            units_file = root / layer / 'units.npy'
+            if units_file.exists():
+                units = numpy.load(units_file)
+                if units.ndim != 1:
+                    raise ValueError(f'expected 1D units, got {units.ndim}D')
+            else:
+                units = numpy.arange(len(images))
+            self.images_by_layer[layer] = images
+            self.masks_by_layer[layer] = masks
+            self.units_by_layer[layer] = units
+            self._index += [(layer, i) for i in range(len(images))]
+        shapes = {self.images_by_layer[l].shape[1:] for l in self.layers}
+        if len(shapes) != 1:
+            raise ValueError(f'layers disagree on (k, 3, H, W): {shapes}')
+
+    def __len__(self) -> int:
+        return len(self._index)
+
+    def __getitem__(self, index: int) -> TopImages:
+        layer, i = self._index[index]
+        images = torch.from_numpy(numpy.array(self.images_by_layer[layer][i]))
+        masks = torch.from_numpy(numpy.array(self.masks_by_layer[layer][i]))
+        # reference datasets.py:191-197: float, images * float32(1/255)
+        mul = torch.tensor(1.0 / 255.0, dtype=torch.float64).to(torch.float32)
+        return TopImages(layer=layer,
+                         unit=int(self.units_by_layer[layer][i]),
+                         images=images.float().mul(mul),
+                         masks=masks.float())
+
+    def slice_uint8(self, lo: int, hi: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Samples [lo, hi) as uint8 (n,k,3,H,W) / (n,k,1,H,W) CPU tensors."""
+        ims, mks = [], []
+        pos = lo
+        while pos < hi:
+            layer, i = self._index[pos]
+            run = min(hi - pos, len(self.images_by_layer[layer]) - i)
+            ims.append(numpy.ascontiguousarray(
+                self.images_by_layer[layer][i:i + run]))
+            mks.append(numpy.ascontiguousarray(
+                self.masks_by_layer[layer][i:i + run]))
+            pos += run
+        images = torch.from_numpy(numpy.concatenate(ims))
+        masks = torch.from_numpy(numpy.concatenate(mks))
+        return images, masks
+
+    def lookup(self, layer: Union[str, int], unit: int) -> TopImages:
+        layer = str(layer)
+        if layer not in self.images_by_layer:
+            raise KeyError(f'layer "{layer}" does not exist')
+        if unit >= len(self.images_by_layer[layer]):
+            raise KeyError(f'layer "{layer}" has no unit {unit}')
+        return self[self._index.index((layer, unit))]
+
+
+def load(key: str, path: Optional[Union[str, pathlib.Path]] = None,
+         **kwargs) -> TopImagesDataset:
+    """`milannotations.load(key, path=...)` for exemplar directories
+    (reference src/milannotations/loaders.py:245-259, local-path branch)."""
+    import os
+    root = pathlib.Path(path) if path is not None else pathlib.Path(
+        os.environ.get('MILAN_DATA_DIR', 'data')) / key
+    if not root.exists():
+        raise KeyError(f'unknown milannotations set: {key}')
+    return TopImagesDataset(root, name=key, **kwargs)

@@ -1,0 +1,464 @@
+"""`src.milan.Decoder` on MI355X: same Python surface, HIP arithmetic.
+
+Reference: `src/milan/decoders.py` -- `Decoder` (:224), `forward` (:335-523),
+`encode` (:525-546), `init_state` (:548-574), `step` (:576-634), `predict`
+(:809-871), `DecoderState/Step/Output` (:84-150), `STRATEGY_*` (:217-221),
+serialisation (:1072-1109).  A script written against the reference (e.g.
+`scripts/compute_milan_descriptions.py:52-63`) runs unchanged after
+`from milan_amd import ...`.
+
+What differs by design:
+  * every tensor op is a call into libmilan_hip (see `hip.py`); there is no
+    torch / CPU fallback -- without a GPU or the .so the calls raise;
+  * inputs may be the reference's float tensors or raw uint8 exemplars
+    (kept uint8 all the way to the GPU: 4x less host memory and PCIe traffic);
+  * `predict` processes `chunk_size` neurons per launch instead of 16, but
+    evaluates allennlp's early-exit length T' per group of `batch_size`
+    neurons, so captions / rerank choices equal the reference's batch-16 run;
+  * out of scope: training (`fit`), `score`/`bleu`/
+    `rouge`/`bert_score` (need spaCy / sacrebleu), 'sample' strategy,
+    `DecoderWithCLIP`.
+"""
+import weakref
+from typing import (Any, Dict, Mapping, NamedTuple, Optional, Sequence, Tuple,
+                    Union)
+
+import torch
+from torch import nn
+from torch.utils import data
+
+from milan_amd import encoders, hip, lang, lms, params, serialize
+
+Strategy = Union[torch.Tensor, str]
+
+STRATEGY_GREEDY = 'greedy'
+STRATEGY_SAMPLE = 'sample'
+STRATEGY_BEAM = 'beam'
+STRATEGY_RERANK = 'rerank'
+STRATEGIES = (STRATEGY_GREEDY, STRATEGY_SAMPLE, STRATEGY_BEAM, STRATEGY_RERANK)
+_HIP_STRATEGY = {
+    STRATEGY_GREEDY: hip.GREEDY,
+    STRATEGY_BEAM: hip.BEAM,
+    STRATEGY_RERANK: hip.RERANK
+}
+
+
+class DecoderState(NamedTuple):
+    """reference decoders.py:84-99."""
+    h: torch.Tensor
+    c: torch.Tensor
+    h_lm: Optional[torch.Tensor]
+    c_lm: Optional[torch.Tensor]
+
+
+class DecoderStep(NamedTuple):
+    """reference decoders.py:102-117."""
+    predictions: torch.Tensor
+    attentions: torch.Tensor
+    state: DecoderState
+
+
+class DecoderOutput(NamedTuple):
+    """reference decoders.py:120-150 (field order matters: captions, scores,
+    tokens; DecoderWithCLIP splats outputs[3:])."""
+    captions: Sequence[str]
+    scores: torch.Tensor
+    tokens: torch.Tensor
+    predictions: Optional[torch.Tensor]
+    attentions: Optional[torch.Tensor]
+    beam_captions: Optional[Sequence[Sequence[str]]]
+    beam_scores: Optional[torch.Tensor]
+    beam_tokens: Optional[torch.Tensor]
+
+
+class Attention(params.ParamTree):
+    """Weights of reference `Attention` (decoders.py:29-81)."""
+
+    def __init__(self,
+                 query_size: int,
+                 key_size: int,
+                 hidden_size: Optional[int] = None):
+        super().__init__()
+        self.query_size = query_size
+        self.key_size = key_size
+        self.hidden_size = hidden_size or min(query_size, key_size)
+        f = torch.float32
+        a = self.hidden_size
+        params.build(
+            {
+                'query_to_hidden.weight': ((a, query_size), f),
+                'query_to_hidden.bias': ((a,), f),
+                'key_to_hidden.weight': ((a, key_size), f),
+                'key_to_hidden.bias': ((a,), f),
+                'output.0.weight': ((1, a), f),
+                'output.0.bias': ((1,), f),
+            },
+            root=self)
+
+
+class Decoder(nn.Module):
+    """Neuron caption decoder (reference decoders.py:224)."""
+
+    def __init__(self,
+                 indexer: lang.Indexer,
+                 encoder: encoders.Encoder,
+                 lm: Optional[lms.LanguageModel] = None,
+                 embedding_size: int = 128,
+                 hidden_size: int = 512,
+                 attention_hidden_size: Optional[int] = None,
+                 dropout: float = .5,
+                 length: int = 15,
+                 strategy: Optional[str] = None,
+                 temperature: float = .2,
+                 beam_size: int = 50):
+        super().__init__()
+        if lm is not None:
+            mine, theirs = indexer.vocab.unique, lm.indexer.vocab.unique
+            if mine != theirs:
+                raise ValueError('lm and decoder have different vocabs;'
+                                 f'lm missing {mine - theirs} and '
+                                 f'decoder missing {theirs - mine}')
+        if strategy is None:
+            strategy = STRATEGY_BEAM if lm is None else STRATEGY_RERANK
+        self.indexer = indexer
+        self.encoder = encoder
+        self.lm = lm
+        self.embedding_size = embedding_size
+        self.hidden_size = hidden_size
+        self.attention_hidden_size = attention_hidden_size
+        self.dropout = dropout
+        self.length = length
+        self.strategy = strategy
+        self.temperature = temperature
+        self.beam_size = beam_size
+        self.chunk_size = 256  # neurons per HIP launch in predict()
+
+        f = torch.float32
+        fs, hs, es, v = (self.feature_size, hidden_size, embedding_size,
+                         self.vocab_size)
+        params.build(
+            {
+                'init_h.0.weight': ((hs, fs), f),
+                'init_h.0.bias': ((hs,), f),
+                'init_c.0.weight': ((hs, fs), f),
+                'init_c.0.bias': ((hs,), f),
+                'embedding.weight': ((v, es), f),
+                'feature_gate.0.weight': ((fs, hs), f),
+                'feature_gate.0.bias': ((fs,), f),
+                'lstm.weight_ih': ((4 * hs, es + fs), f),
+                'lstm.weight_hh': ((4 * hs, hs), f),
+                'lstm.bias_ih': ((4 * hs,), f),
+                'lstm.bias_hh': ((4 * hs,), f),
+                'output.1.weight': ((v, hs), f),
+                'output.1.bias': ((v,), f),
+            },
+            root=self)
+        self.attend = Attention(hidden_size,
+                                fs,
+                                hidden_size=attention_hidden_size)
+        if lm is not None:
+            lm._owner = weakref.ref(self)
+        self._ctx: Optional[hip.Context] = None
+        self._ctx_key = None
+        self.eval()  # hubs.py:130 hands out models in eval mode
+
+    # -- reference properties -------------------------------------------------
+    @property
+    def feature_size(self) -> int:
+        return self.encoder.feature_shape[-1]
+
+    @property
+    def vocab_size(self) -> int:
+        return len(self.indexer)
+
+    @property
+    def device(self) -> torch.device:
+        return self.embedding.weight.device
+
+    # -- HIP context -------------------------------------------------------------
+    def _has_hip_encoder(self) -> bool:
+        return isinstance(self.encoder, encoders.PyramidConvEncoder)
+
+    def _context(self) -> hip.Context:
+        """(Re)build the packed-weight context when device or weights change."""
+        device = hip.require_device(self.device)
+        key = (device, tuple(p._version for p in self.parameters()),
+               tuple(b._version for b in self.buffers()))
+        if self._ctx is None or self._ctx_key != key:
+            sd = dict(self.state_dict())
+            blocks = (3, 4, 23, 3)
+            if self._has_hip_encoder():
+                blocks = self.encoder.blocks
+            else:  # foreign Encoder subclass: only decoder weights go native
+                sd = {k: v for k, v in sd.items() if not k.startswith('encoder.')}
+            dims = hip.make_dims(sd, len(self.indexer.vocab), blocks=blocks)
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = hip.Context(dims, sd, device)
+            self._ctx_key = key
+        return self._ctx
+
+    # -- forward -------------------------------------------------------------------
+    def forward(self,
+                images_or_features: torch.Tensor,
+                masks: Optional[torch.Tensor] = None,
+                encode: Optional[bool] = None,
+                length: Optional[int] = None,
+                strategy: Optional[Strategy] = None,
+                mi: Optional[bool] = None,
+                temperature: Optional[float] = None,
+                beam_size: Optional[int] = None,
+                group_size: Optional[int] = None) -> DecoderOutput:
+        """Decode captions for top images + masks (reference :335-523).
+
+        `group_size` (extension, default = the whole batch like the
+        reference): neurons per allennlp early-exit group, see `predict`.
+        """
+        if encode is None:
+            encode = masks is not None
+        if length is None:
+            length = self.length
+        if strategy is None:
+            strategy = self.strategy
+        if mi is None:
+            mi = self.lm is not None and not self.training
+            mi &= not isinstance(strategy, str) or strategy != STRATEGY_RERANK
+        if temperature is None:
+            temperature = self.temperature
+        if beam_size is None:
+            beam_size = self.beam_size
+        batch_size = len(images_or_features)
+
+        # Validate arguments (reference :395-409).
+        if mi and isinstance(strategy, str) and strategy == STRATEGY_RERANK:
+            raise ValueError('cannot set `mi=` decoding when reranking')
+        rerank = isinstance(strategy, str) and strategy == STRATEGY_RERANK
+        if (mi or rerank) and self.lm is None:
+            raise ValueError('cannot use MI/rerank decoding without an LM')
+        if (mi or rerank) and self.training:
+            raise ValueError('cannot use MI/rerank decoding while training')
+        if isinstance(strategy, str) and strategy not in STRATEGIES:
+            raise ValueError(f'unknown strategy: {strategy}')
+        if isinstance(strategy, torch.Tensor):
+            if strategy.dim() != 2:
+                raise ValueError(f'strategy must be 2D, got {strategy.dim()}')
+            if strategy.shape[-1] != length:
+                raise ValueError(f'strategy must have length {length}, '
+                                 f'got {strategy.shape[-1]}')
+            raise NotImplementedError(
+                'teacher forcing (strategy=<tensor>) belongs to training / '
+                'Decoder.score and is outside the MI355X inference path')
+        if strategy == STRATEGY_SAMPLE:
+            raise NotImplementedError(
+                "strategy='sample' is outside the MI355X inference path")
+        if self.training:
+            raise NotImplementedError(
+                'training-mode forward (dropout active) is not built; call '
+                '.eval() -- milan.pretrained() returns eval-mode models')
+
+        ctx = self._context()
+        hip_strategy = _HIP_STRATEGY[strategy]
+        full = hip_strategy == hip.GREEDY
+        gs = group_size or 0
+        if encode and self._has_hip_encoder():
+            images = images_or_features
+            if images.dim() == 4:  # (B,3,H,W): one exemplar per sample
+                images = images.unsqueeze(1)
+                masks = None if masks is None else masks.unsqueeze(1)
+            out = ctx.describe(images, masks, hip_strategy, length, beam_size,
+                               mi, temperature, group_size=gs, want_full=full)
+        else:
+            if encode:
+                features = self.encode(images_or_features, masks=masks)
+            else:
+                features = images_or_features
+            out = ctx.decode(features, hip_strategy, length, beam_size, mi,
+                             temperature, group_size=gs, want_full=full)
+
+        tokens, scores = out['tokens'], out['scores']
+        beam_captions = beam_scores = beam_tokens = None
+        if hip_strategy != hip.GREEDY:
+            # allennlp returns T' <= length columns; with several groups the
+            # tensors keep the longest group's T' (shorter groups are padded
+            # with <stop>, which reconstruct() ignores).
+            tprime = int(out['out_len'].max().item())
+            tokens = tokens[:, :tprime]
+            beam_tokens = out['beam_tokens'][:, :, :tprime]
+            beam_scores = out['beam_scores']
+            beam_captions = lang.LazyCaptions(self.indexer, beam_tokens)
+        assert len(tokens) == batch_size
+        return DecoderOutput(
+            captions=self.indexer.reconstruct(tokens.tolist()),
+            scores=scores,
+            tokens=tokens,
+            predictions=out['predictions'],
+            attentions=out['attentions'],
+            beam_captions=beam_captions,
+            beam_scores=beam_scores,
+            beam_tokens=beam_tokens,
+        )
+
+    def encode(self,
+               images: torch.Tensor,
+               masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Images+masks -> (B, k, F) features (reference :525-546)."""
+        batch_size = len(images)
+        images = images.reshape(-1, *images.shape[-3:])
+        if masks is not None:
+            masks = masks.reshape(-1, *masks.shape[-3:])
+        if self._has_hip_encoder():
+            features = self._context().encode(images, masks)
+        else:
+            features = self.encoder(images, masks=masks)
+        return features.view(batch_size, -1, self.feature_size)
+
+    def init_state(self, features: torch.Tensor, lm: bool = True) -> DecoderState:
+        """reference :548-574."""
+        h, c = self._context().init_state(features)
+        h_lm = c_lm = None
+        if self.lm is not None and lm:
+            batch_size = len(features)
+            h_lm = h.new_zeros(self.lm.layers, batch_size, self.lm.hidden_size)
+            c_lm = c.new_zeros(self.lm.layers, batch_size, self.lm.hidden_size)
+        return DecoderState(h, c, h_lm, c_lm)
+
+    def step(self,
+             features: torch.Tensor,
+             tokens: torch.Tensor,
+             state: DecoderState,
+             temperature: Optional[float] = None) -> DecoderStep:
+        """One decoding step (reference :576-634)."""
+        h, c, h_lm, c_lm = state
+        if (h_lm is None) != (c_lm is None):
+            raise ValueError('state must have both h_lm and c_lm or neither')
+        if h_lm is not None and self.lm is None:
+            raise ValueError('state has h_lm or c_lm, but decoder has no lm')
+        temperature = self.temperature if temperature is None else temperature
+        pred, att, h2, c2, h_lm, c_lm = self._context().step(
+            features, tokens, h, c, h_lm, c_lm, temperature)
+        return DecoderStep(predictions=pred,
+                           attentions=att,
+                           state=DecoderState(h=h2, c=c2, h_lm=h_lm, c_lm=c_lm))
+
+    # -- dataset driver ---------------------------------------------------------------
+    def predict(self,
+                dataset: data.Dataset,
+                mask: bool = True,
+                image_index: int = 2,
+                mask_index: int = 3,
+                batch_size: int = 16,
+                features: Optional[data.TensorDataset] = None,
+                num_workers: int = 0,
+                device: Optional[Union[str, torch.device]] = None,
+                display_progress_as: Optional[str] = 'predict captions',
+                **kwargs: Any) -> Tuple[str, ...]:
+        """Feed an entire dataset through the decoder (reference :809-871).
+
+        Same arguments and return value.  `batch_size` keeps its meaning for
+        the result (allennlp's early exit is evaluated per `batch_size`
+        neurons) but the GPU is fed `self.chunk_size` neurons at a time.
+        """
+        if device is not None:
+            self.to(device)
+        chunk = max(batch_size, (self.chunk_size // batch_size) * batch_size)
+        source = dataset if features is None else features
+        fast = getattr(source, 'slice_uint8', None) if features is None else None
+        captions = []
+        n = len(source)
+        spans = range(0, n, chunk)
+        if display_progress_as is not None:
+            try:
+                from tqdm.auto import tqdm
+                spans = tqdm(spans, desc=display_progress_as)
+            except ImportError:
+                pass
+        for lo in spans:
+            hi = min(n, lo + chunk)
+            if fast is not None:  # memory-mapped uint8 dataset: no collate
+                images, masks = fast(lo, hi)
+                inputs = (images, masks if mask else None)
+            else:
+                loader = data.DataLoader(data.Subset(source, range(lo, hi)),
+                                         batch_size=hi - lo,
+                                         num_workers=num_workers)
+                batch = next(iter(loader))
+                if features is None:
+                    inputs = (batch[image_index],
+                              batch[mask_index] if mask else None)
+                else:
+                    inputs = tuple(batch)
+            with torch.no_grad():
+                output = self(*inputs, group_size=batch_size, **kwargs)
+            captions += list(output.captions)
+        return tuple(captions)
+
+    # -- serialisation (reference serialize.py:175-269, decoders.py:1072-1109) ---------
+    def properties(self) -> Mapping[str, Any]:
+        return {
+            'indexer': self.indexer,
+            'encoder': self.encoder,
+            'lm': self.lm,
+            'embedding_size': self.embedding_size,
+            'hidden_size': self.hidden_size,
+            'attention_hidden_size': self.attention_hidden_size,
+            'dropout': self.dropout,
+            'length': self.length,
+            'strategy': self.strategy,
+            'temperature': self.temperature,
+            'beam_size': self.beam_size,
+        }
+
+    def serialize(self, state_dict: bool = True) -> Dict[str, Any]:
+        def ser(obj):
+            if obj is None or not hasattr(obj, 'properties'):
+                return obj
+            return serialize.serialized(
+                {k: ser(v) for k, v in obj.properties().items()})
+
+        out = serialize.serialized(
+            {k: ser(v) for k, v in self.properties().items()},
+            {'encoder': encoders.key(self.encoder)})
+        if state_dict:
+            out['state_dict'] = self.state_dict()
+        return out
+
+    def save(self, file, **kwargs: Any) -> None:
+        torch.save(self.serialize(**kwargs), file)
+
+    @classmethod
+    def deserialize(cls,
+                    payload: Mapping[str, Any],
+                    strict: bool = False,
+                    load_state_dict: bool = True) -> 'Decoder':
+        payload = dict(payload)
+        state_dict = payload.pop('state_dict', None)
+        p = dict(serialize.props(payload))
+        children = payload.get('children') or {}
+        encoder_key = children.get('encoder')
+        if encoder_key is None:
+            raise ValueError('serialized decoder missing encoder')
+
+        def make_indexer(node) -> lang.Indexer:
+            ip = dict(serialize.props(node))
+            vocab = lang.Vocab(tuple(serialize.props(ip.pop('vocab'))['tokens']))
+            tokenize = ip.pop('tokenize', None)
+            return lang.Indexer(vocab, tokenize, **ip)
+
+        indexer = make_indexer(p.pop('indexer'))
+        enc_node = p.pop('encoder')
+        encoder = encoders.parse(encoder_key)(**serialize.props(enc_node))
+        lm = None
+        lm_node = p.pop('lm', None)
+        if lm_node is not None:
+            lp = dict(serialize.props(lm_node))
+            lm = lms.LanguageModel(make_indexer(lp.pop('indexer')), **lp)
+        module = cls(indexer, encoder, lm=lm, **p)
+        if state_dict is not None and load_state_dict:
+            module.load_state_dict(state_dict, strict=strict)
+        return module
+
+    @classmethod
+    def load(cls, file, **kwargs: Any) -> 'Decoder':
+        """Load a reference-format checkpoint (serialize.py:255-269).
+        Keyword arguments are forwarded to `torch.load`."""
+        return cls.deserialize(serialize.load_payload(file, **kwargs))

@@ -1,0 +1,170 @@
+"""Visual encoders: the reference's `src/milan/encoders.py` surface on HIP.
+
+`Encoder` keeps the reference's abstract contract (feature_shape, forward(images,
+masks=None) -> (M, *feature_shape), map(dataset) -> TensorDataset;
+encoders.py:23-148) so any subclass -- including a caller's own, like the
+reference's test FakeEncoder -- still plugs into `Decoder`.
+`PyramidConvEncoder` (encoders.py:243-351) is the one pretrained MILAN uses;
+its arithmetic runs in libmilan_hip (`milan_encode`).  Bottleneck ResNet
+configs only (resnet50 / resnet101 / resnet152-shaped); the reference's
+`alexnet` / `resnet18` pyramid configs and `SpatialConvEncoder` use other
+trunks and are out of scope (ValueError, same type the reference raises for
+an unsupported config, encoders.py:265-267).
+"""
+from typing import Any, Mapping, Optional, Tuple, Type, Union
+
+import torch
+from torch import nn
+from torch.utils import data
+
+from milan_amd import hip, params, synthetic
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)  # src/deps/netdissect/renormalize.py:87
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class Encoder(nn.Module):
+    """Abstract module mapping images (and optionally masks) to features."""
+
+    feature_shape: Tuple[int, ...]
+
+    def forward(self,
+                images: torch.Tensor,
+                masks: Optional[torch.Tensor] = None,
+                **kwargs: Any) -> torch.Tensor:
+        raise NotImplementedError
+
+    def properties(self) -> Mapping[str, Any]:
+        raise NotImplementedError
+
+    def map(self,
+            dataset: data.Dataset,
+            mask: bool = True,
+            image_index: Union[int, str] = -3,
+            mask_index: Union[int, str] = -2,
+            batch_size: int = 64,
+            num_workers: int = 0,
+            device: Optional[Union[str, torch.device]] = None,
+            display_progress_as: Union[bool, str] = True,
+            **kwargs: Any) -> data.TensorDataset:
+        """Featurize an entire dataset (reference encoders.py:61-148)."""
+        if device is not None:
+            self.to(device)
+        mapped = []
+        loader = data.DataLoader(dataset,
+                                 batch_size=batch_size,
+                                 num_workers=num_workers)
+        if isinstance(display_progress_as, str) or display_progress_as:
+            try:
+                from tqdm.auto import tqdm
+                desc = (display_progress_as if isinstance(
+                    display_progress_as, str) else 'featurize dataset')
+                loader = tqdm(loader, desc=desc)
+            except ImportError:
+                pass
+        for batch in loader:
+            images = batch[image_index]
+            if not isinstance(images, torch.Tensor):
+                raise ValueError(f'non-tensor images: {type(images).__name__}')
+            inputs = [images.view(-1, *images.shape[-3:])]
+            if mask:
+                masks = batch[mask_index]
+                if not isinstance(masks, torch.Tensor):
+                    raise ValueError(
+                        f'non-tensor masks: {type(masks).__name__}')
+                inputs.append(masks.view(-1, *masks.shape[-3:]))
+            with torch.no_grad():
+                features = self(*inputs, **kwargs)
+            features = features.view(*images.shape[:-3], *self.feature_shape)
+            mapped.append(features)
+        return data.TensorDataset(torch.cat(mapped))
+
+
+class PyramidConvEncoder(Encoder):
+    """Masked multi-resolution ResNet features (reference encoders.py:243).
+
+    Owns `encoder.model.*` (torchvision key names), `mean`, `std`.  Extra
+    keyword arguments (`pretrained=`, ...) are kept for serialisation only:
+    there is no torchvision download here, weights come from the checkpoint.
+    """
+
+    def __init__(self, config: str = 'resnet50', **kwargs: Any):
+        super().__init__()
+        configs = PyramidConvEncoder.configs()
+        if config not in configs:
+            raise ValueError(f'encoder not supported: {config}')
+        self.config = config
+        self.kwargs = dict(kwargs)
+        self.kwargs.setdefault('pretrained', True)
+        self.width = int(self.kwargs.get('width', 64))
+        self.blocks, self.layers = configs[config]
+        self.feature_shape = (61 * self.width,)
+        self.encoder = params.ParamTree()
+        params.build(params.resnet_spec(self.blocks, self.width, 'model.'),
+                     root=self.encoder)
+        self.register_buffer('mean',
+                             torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1))
+        self.register_buffer('std', torch.tensor(IMAGENET_STD).view(1, 3, 1, 1))
+        self._ctx: Optional[hip.Context] = None
+        self._ctx_key = None
+
+    # -- HIP context (encoder used stand-alone, e.g. Encoder.map) -------------
+    def _context(self) -> hip.Context:
+        device = hip.require_device(self.mean.device)
+        key = (device, tuple(p._version for p in self.parameters()))
+        if self._ctx is None or self._ctx_key != key:
+            sd = {'encoder.' + k: v for k, v in self.state_dict().items()}
+            dims = hip.make_dims(sd, 1, blocks=self.blocks)
+            self._ctx = hip.Context(dims, sd, device)
+            self._ctx_key = key
+        return self._ctx
+
+    def forward(self,
+                images: torch.Tensor,
+                masks: Optional[torch.Tensor] = None,
+                normalize: bool = True,
+                **_: Any) -> torch.Tensor:
+        """Construct pyramid features: (M,3,H,W) [+ (M,1,H,W)] -> (M, F).
+
+        Accepts the reference's float tensors (images in [0,1]) or raw uint8
+        exemplars (converted on the GPU exactly like the reference's loader).
+        """
+        if not normalize:
+            raise ValueError('normalize=False is not supported by the HIP '
+                             'encoder (normalisation is fused into the input '
+                             'conversion kernel)')
+        return self._context().encode(images, masks)
+
+    def properties(self) -> Mapping[str, Any]:
+        return {'config': self.config, **self.kwargs}
+
+    @staticmethod
+    def configs():
+        layers = ('conv1', 'layer1', 'layer2', 'layer3', 'layer4')
+        return {
+            name: (blocks, layers)
+            for name, blocks in synthetic.RESNET_BLOCKS.items()
+        }
+
+
+def parse(key: str) -> Type[Encoder]:
+    """Parse the string key into an encoder type (reference :354-359)."""
+    try:
+        return {'PyramidConvEncoder': PyramidConvEncoder}[key]
+    except KeyError:
+        raise KeyError(
+            f'{key}: only PyramidConvEncoder is built for MI355X') from None
+
+
+def key(encoder: Encoder) -> str:
+    return type(encoder).__name__
+
+
+KIND_PYRAMID = 'pyramid'
+
+
+def encoder(kind: str = KIND_PYRAMID, **kwargs: Any) -> Encoder:
+    """Create an encoder (reference :371-391)."""
+    if kind == KIND_PYRAMID:
+        return PyramidConvEncoder(**kwargs)
+    return parse(kind)(**kwargs)

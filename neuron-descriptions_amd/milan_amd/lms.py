@@ -1,0 +1,68 @@
+"""The LSTM language model used for PMI decoding / reranking.
+
+Mirror of the reference's `src/milan/lms.py:17-101` (inference surface):
+Embedding(V,E,padding_idx) -> 2-layer LSTM -> Linear(V) + LogSoftmax, and
+`forward(inputs, reduce=True)` = masked sequence log-probability with the
+reference's stop-mask off-by-one (lms.py:93-96).  Training (`fit`) and text
+scoring (`logp`, needs the spaCy tokenizer) are out of scope.
+"""
+from typing import Any, Mapping, Optional
+
+import torch
+from torch import nn
+
+from milan_amd import hip, lang, params
+
+
+class LanguageModel(nn.Module):
+    """Parameter owner + HIP entry point for the LM."""
+
+    def __init__(self,
+                 indexer: lang.Indexer,
+                 embedding_size: int = 128,
+                 hidden_size: int = 512,
+                 layers: int = 2,
+                 dropout: float = .5):
+        super().__init__()
+        self.indexer = indexer
+        self.embedding_size = embedding_size
+        self.hidden_size = hidden_size
+        self.layers = layers
+        self.dropout = dropout
+        f = torch.float32
+        v, e, h = len(indexer), embedding_size, hidden_size
+        spec = {'embedding.weight': ((v, e), f)}
+        for layer in range(layers):
+            spec[f'lstm.weight_ih_l{layer}'] = ((4 * h, e if layer == 0 else h),
+                                                f)
+            spec[f'lstm.weight_hh_l{layer}'] = ((4 * h, h), f)
+            spec[f'lstm.bias_ih_l{layer}'] = ((4 * h,), f)
+            spec[f'lstm.bias_hh_l{layer}'] = ((4 * h,), f)
+        spec['output.0.weight'] = ((v, h), f)
+        spec['output.0.bias'] = ((v,), f)
+        params.build(spec, root=self)
+        self._owner = None  # set by Decoder: scoring runs in its HIP context
+
+    def forward(self,
+                inputs: torch.Tensor,
+                reduce: bool = False,
+                masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Sequence log-probabilities (reference lms.py:58-101, reduce=True)."""
+        if not reduce or masks is not None:
+            raise NotImplementedError(
+                'only forward(inputs, reduce=True) with the default stop mask '
+                'is on the inference path (src/milan/decoders.py:504)')
+        if self._owner is None:
+            raise hip.HipUnavailableError(
+                'LanguageModel scores through its Decoder\'s HIP context; '
+                'attach it to a milan_amd.Decoder first')
+        return self._owner()._context().lm_score(inputs)
+
+    def properties(self) -> Mapping[str, Any]:
+        return {
+            'indexer': self.indexer,
+            'embedding_size': self.embedding_size,
+            'hidden_size': self.hidden_size,
+            'layers': self.layers,
+            'dropout': self.dropout,
+        }

@@ -1,0 +1,331 @@
+"""CPU-only tests of the host side: C-ABI surface, caption reconstruction,
+checkpoint format, the Python mirror's error behaviour, sharding (gloo)."""
+import ctypes
+import os
+import pathlib
+import re
+import subprocess
+import sys
+
+import numpy
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from milan_amd import (datasets, decoders, encoders, hip, lang, lms, loaders,
+                       serialize, sharding, synthetic)
+
+REPO = pathlib.Path(__file__).resolve().parent.parent
+HEADER = REPO / 'include' / 'milan_hip.h'
+
+
+# ---- C ABI -----------------------------------------------------------------
+def header_symbols():
+    text = re.sub(r'/\*.*?\*/', '', HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r'\b(milan_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_header_symbol():
+    """The .so loads (no GPU needed) and exports exactly what the header
+    declares; the ctypes table covers all of it."""
+    syms = header_symbols()
+    assert 'milan_describe' in syms and 'milan_decode' in syms
+    lib = hip.load_library()
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in milan_hip.h but not exported'
+    assert sorted(hip.SIGNATURES) == syms
+    assert lib.milan_abi_version() == 1
+    out = subprocess.run(['nm', '-D', '--defined-only', str(hip.LIB_PATH)],
+                         capture_output=True, text=True, check=True).stdout
+    exported = sorted(
+        set(re.findall(r' T (milan_[a-z0-9_]+)$', out, flags=re.M)))
+    assert exported == syms, 'undocumented or missing C-ABI exports'
+
+
+def test_dims_struct_matches_header_layout():
+    text = HEADER.read_text()
+    body = text[text.index('typedef struct milan_dims {'):text.
+                index('} milan_dims;')]
+    fields = re.findall(r'int32_t\s+([a-z_]+)(\[4\])?;', body)
+    assert [f for f, _ in fields] == [n for n, _ in hip.Dims._fields_]
+    assert ctypes.sizeof(hip.Dims) == 4 * (len(fields) + 3)
+
+
+def test_missing_library_is_loud(tmp_path):
+    with pytest.raises(hip.HipUnavailableError, match='no CPU fallback'):
+        hip.load_library(tmp_path / 'libmilan_hip.so')
+
+
+def test_argument_errors_need_no_gpu():
+    lib = hip.load_library()
+    assert lib.milan_create(None, 0, None) == hip.ERR_ARG
+    assert b'null argument' in lib.milan_last_error()
+    d = hip.Dims()
+    h = ctypes.c_void_p()
+    assert lib.milan_create(ctypes.byref(h), 0, ctypes.byref(d)) == hip.ERR_SHAPE
+    assert lib.milan_workspace_bytes(None, 1, 1, 224, 1, 1) == 0
+
+
+# ---- no silent CPU path --------------------------------------------------------
+def tiny_decoder(lm=True, encoder=None):
+    idx = lang.Indexer(lang.Vocab(synthetic.vocab_tokens(12)), None, True,
+                       True, True, True, 15)
+    enc = encoder or encoders.PyramidConvEncoder(
+        'resnet50', width=8, pretrained=False)
+    model = lms.LanguageModel(idx, 4, 8) if lm else None
+    return decoders.Decoder(idx, enc, model, embedding_size=4, hidden_size=8)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only behaviour')
+def test_product_path_fails_loudly_without_gpu():
+    d = tiny_decoder()
+    feats = torch.rand(2, 3, d.feature_size)
+    with pytest.raises(hip.HipUnavailableError, match='no CPU fallback'):
+        d(feats, strategy='greedy')
+    with pytest.raises(hip.HipUnavailableError):
+        d.init_state(feats)
+    with pytest.raises(hip.HipUnavailableError):
+        d.encoder(torch.rand(1, 3, 64, 64))
+    with pytest.raises(hip.HipUnavailableError):
+        d.lm(torch.zeros(1, 4, dtype=torch.long), reduce=True)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = REPO / 'neuron-descriptions_amd'
+    for path in list(pkg.rglob('*.py')) + list(pkg.rglob('*.hip')) + list(
+            pkg.rglob('*.h')):
+        text = path.read_text()
+        assert 'milan_oracle' not in text and 'import oracle' not in text \
+            and 'from oracle' not in text, path
+
+
+# ---- reference error conventions (decoders.py:395-409, encoders.py:265) ------
+def test_forward_validation_matches_reference():
+    d = tiny_decoder(lm=False)
+    feats = torch.rand(2, 3, d.feature_size)
+    with pytest.raises(ValueError, match='without an LM'):
+        d(feats, strategy='rerank')
+    with pytest.raises(ValueError, match='without an LM'):
+        d(feats, strategy='greedy', mi=True)
+    with pytest.raises(ValueError, match='unknown strategy: nope'):
+        d(feats, strategy='nope')
+    with pytest.raises(ValueError, match='strategy must be 2D'):
+        d(feats, strategy=torch.zeros(3, dtype=torch.long))
+    with pytest.raises(ValueError, match='strategy must have length 15'):
+        d(feats, strategy=torch.zeros(2, 4, dtype=torch.long))
+    d2 = tiny_decoder(lm=True)
+    with pytest.raises(ValueError, match='cannot set `mi=` decoding'):
+        d2(feats, strategy='rerank', mi=True)
+    d2.train()
+    with pytest.raises(ValueError, match='while training'):
+        d2(feats, strategy='rerank')
+    with pytest.raises(ValueError, match='encoder not supported: bad-config'):
+        encoders.PyramidConvEncoder(config='bad-config')
+    st = decoders.DecoderState(torch.zeros(2, 8), torch.zeros(2, 8),
+                               torch.zeros(2, 2, 8), None)
+    with pytest.raises(ValueError, match='both h_lm and c_lm'):
+        d2.step(feats, torch.zeros(2, dtype=torch.long), st)
+
+
+def test_defaults_and_attributes_match_reference():
+    d = tiny_decoder()
+    assert d.strategy == 'rerank' and d.beam_size == 50 and d.length == 15
+    assert d.temperature == .2 and not d.training
+    assert tiny_decoder(lm=False).strategy == 'beam'
+    assert d.vocab_size == 16 and d.feature_size == 61 * 8
+    assert d.indexer.start_index == 12 and d.indexer.stop_index == 13
+    assert d.indexer.pad_index == 14 and d.indexer.unk_index == 15
+    assert decoders.STRATEGIES == ('greedy', 'sample', 'beam', 'rerank')
+    assert decoders.DecoderOutput._fields[:3] == ('captions', 'scores',
+                                                  'tokens')
+
+
+def test_vocab_mismatch_raises_like_reference():
+    idx = lang.Indexer(lang.Vocab(('a', 'b')), None)
+    other = lang.Indexer(lang.Vocab(('a', 'c')), None)
+    enc = encoders.PyramidConvEncoder('resnet50', width=8)
+    with pytest.raises(ValueError, match='different vocabs'):
+        decoders.Decoder(idx, enc, lms.LanguageModel(other, 4, 8),
+                         embedding_size=4, hidden_size=8)
+
+
+# ---- captions ------------------------------------------------------------------
+def test_reconstruct_matches_reference_table(golden_meta):
+    idx = lang.Indexer(lang.Vocab(tuple(golden_meta['g6_vocab'])), None)
+    for case, want in zip(golden_meta['g6_cases'], golden_meta['g6_expected']):
+        assert idx.reconstruct(case) == want
+    assert list(idx.reconstruct(
+        golden_meta['g6_cases'])) == golden_meta['g6_expected_batch']
+    for case, want in zip(golden_meta['g6_cases'], golden_meta['g6_unindex']):
+        assert list(idx.unindex(case)) == want
+    with pytest.raises(ValueError, match='unknown index: 99'):
+        idx.reconstruct([5, 99])
+    with pytest.raises(ValueError, match='at least one seq'):
+        idx.reconstruct([])
+    with pytest.raises(ValueError, match='input seq 1 is empty'):
+        idx.reconstruct([[1], []])
+    assert idx.reconstruct(['the', 'dog', '.']) == 'The dog.'
+    lazy = lang.LazyCaptions(idx, torch.tensor([[[5, 8, 13], [8, 13, 13]]]))
+    assert len(lazy) == 1 and lazy[0] == ('The dog', 'Dog')
+
+
+# ---- checkpoints ----------------------------------------------------------------
+def test_state_dict_names_match_reference_skeleton(golden_meta):
+    """Every parameter name/shape of the reference Decoder (G7) exists here."""
+    skel = golden_meta['g7_skeleton']
+    idx = lang.Indexer(lang.Vocab(synthetic.vocab_tokens(12)), None, True,
+                       True, True, True, 15)
+
+    class Fake(encoders.Encoder):
+        feature_shape = (61,)
+
+        def properties(self):
+            return {'feature_size': 61}
+
+    d = decoders.Decoder(idx, Fake(), lms.LanguageModel(idx, 4, 8),
+                         embedding_size=4, hidden_size=8)
+    mine = {k: f'tensor{tuple(v.shape)}:{v.dtype}'
+            for k, v in d.state_dict().items()}
+    assert mine == skel['state_dict']
+    ser = d.serialize(state_dict=False)
+    assert set(ser['properties']) == set(skel['properties'])
+    assert set(ser['properties']['indexer']['properties']) == set(
+        skel['properties']['indexer']['properties'])
+
+
+def test_checkpoint_roundtrip_and_foreign_pickles(tmp_path):
+    d = tiny_decoder()
+    sd = synthetic.milan_state_dict(16, 'resnet50', seed=3, width=8,
+                                    hidden_size=8, embedding_size=4,
+                                    lm_hidden_size=8, lm_embedding_size=4)
+    missing = d.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    path = tmp_path / 'milan-base.pth'
+    d.save(path)
+    back = decoders.Decoder.load(path)
+    assert not back.training
+    for k, v in d.state_dict().items():
+        assert torch.equal(v, back.state_dict()[k]), k
+    assert back.indexer.vocab.tokens == d.indexer.vocab.tokens
+    assert back.encoder.config == 'resnet50' and back.encoder.width == 8
+
+    # a reference checkpoint pickles spaCy/thinc objects we cannot import
+    payload = d.serialize()
+    import types
+    mod = types.ModuleType('thinc_not_installed')
+
+    Config = type('Config', (dict,), {
+        '__module__': 'thinc_not_installed',
+        '__qualname__': 'Config'
+    })
+    mod.Config = Config
+    sys.modules['thinc_not_installed'] = mod
+    try:
+        payload['properties']['indexer']['properties']['tokenize'] = {
+            'properties': {'nlp': (Config(lang='en'), b'\x00spacy-bytes'),
+                           'lemmatize': False},
+            'children': {}}
+        torch.save(payload, path)
+    finally:
+        del sys.modules['thinc_not_installed']
+    back = decoders.Decoder.load(path)  # must not need thinc
+    assert back.indexer.tokenize['properties']['lemmatize'] is False
+
+    os.environ['MILAN_MODELS_DIR'] = str(tmp_path)
+    try:
+        assert isinstance(loaders.pretrained('base'), decoders.Decoder)
+        with pytest.raises(KeyError, match='no such model in hub'):
+            loaders.pretrained('nonsense')
+        (tmp_path / 'milan-base.pth').unlink()
+        with pytest.raises(FileNotFoundError):
+            loaders.pretrained('base')
+    finally:
+        del os.environ['MILAN_MODELS_DIR']
+    with pytest.raises(ValueError, match='not a serialized MILAN module'):
+        torch.save({'x': 1}, path)
+        decoders.Decoder.load(path)
+
+
+# ---- dataset -----------------------------------------------------------------
+def test_top_images_dataset_contract(tmp_path):
+    """Same on-disk format and validation as the reference loader
+    (src/milannotations/datasets.py:159-197; tests/conftest.py:74-85)."""
+    rng = numpy.random.default_rng(0)
+    for layer, units in (('layer1', 3), ('layer2', 2)):
+        (tmp_path / layer).mkdir()
+        numpy.save(tmp_path / layer / 'images.npy',
+                   rng.integers(0, 256, (units, 5, 3, 16, 16), dtype=numpy.uint8))
+        numpy.save(tmp_path / layer / 'masks.npy',
+                   rng.integers(0, 2, (units, 5, 1, 16, 16), dtype=numpy.uint8))
+    numpy.save(tmp_path / 'layer2' / 'units.npy', numpy.array([7, 9]))
+    ds = datasets.TopImagesDataset(tmp_path)
+    assert len(ds) == 5 and ds.layers == ('layer1', 'layer2')
+    s = ds[4]
+    assert (s.layer, s.unit) == ('layer2', 9)
+    assert s.images.dtype == torch.float32 and s.images.shape == (5, 3, 16, 16)
+    assert float(s.images.max()) <= 1.0 and set(s.masks.unique().tolist()) <= {0., 1.}
+    im, mk = ds.slice_uint8(1, 5)  # spans the layer boundary
+    assert im.dtype == torch.uint8 and im.shape == (4, 5, 3, 16, 16)
+    mul = torch.tensor(1 / 255, dtype=torch.float64).float()
+    assert torch.equal(im[3].float().mul(mul), s.images)
+    assert torch.equal(mk[3].float(), s.masks)
+    assert ds.lookup('layer2', 1).unit == 9
+    with pytest.raises(KeyError):
+        ds.lookup('nope', 0)
+    with pytest.raises(FileNotFoundError):
+        datasets.TopImagesDataset(tmp_path / 'missing')
+    (tmp_path / 'layer3').mkdir()
+    with pytest.raises(FileNotFoundError, match='missing images.npy'):
+        datasets.TopImagesDataset(tmp_path)
+
+
+# ---- sharding ------------------------------------------------------------------
+def test_partition_is_contiguous_and_complete():
+    for n in (0, 1, 7, 8, 4096, 1153):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.partition(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d
+            assert max(b - a for a, b in spans) == -(-n // world)
+    with pytest.raises(ValueError):
+        sharding.partition(4, 2, 2)
+
+
+def _gloo_worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    r, w, _ = sharding.init_from_env(world, backend='gloo')
+    dev = torch.device('cpu')
+    sd = synthetic.decoder_state_dict(20, feature_size=244, hidden_size=8,
+                                      embedding_size=4, lm_hidden_size=8,
+                                      lm_embedding_size=4) if r == 0 else None
+    if r == 0:
+        sd['encoder.encoder.model.bn1.num_batches_tracked'] = torch.tensor(5)
+    got = sharding.broadcast_state_dict(sd, dev, src=0)
+    ref = synthetic.decoder_state_dict(20, feature_size=244, hidden_size=8,
+                                       embedding_size=4, lm_hidden_size=8,
+                                       lm_embedding_size=4)
+    ok = all(torch.equal(got[k], v) for k, v in ref.items())
+    ok &= int(got['encoder.encoder.model.bn1.num_batches_tracked']) == 5
+    ok &= got['encoder.encoder.model.bn1.num_batches_tracked'].dtype == torch.int64
+    ok &= list(got)[:len(ref)] == list(ref)
+    # ragged shards: 7 neurons over 2 ranks -> 4 + 3
+    lo, hi = sharding.partition(7, w, r)
+    tokens = torch.arange(lo, hi).view(-1, 1).repeat(1, 3)
+    scores = torch.arange(lo, hi).float()
+    t, s = sharding.gather_results(tokens, scores, dst=0)
+    if r == 0:
+        ok &= torch.equal(t[:, 0], torch.arange(7)) and torch.equal(
+            s, torch.arange(7.))
+    ok &= sharding.max_over_ranks(float(r), dev) == float(w - 1)
+    sharding.finalize()
+    pathlib.Path(tmp, f'ok{rank}').write_text(str(bool(ok)))
+
+
+def test_world_size_two_broadcast_and_gather_over_gloo(tmp_path):
+    port = 29000 + os.getpid() % 1000
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').read_text() == 'True'
+    assert (tmp_path / 'ok1').read_text() == 'True'
