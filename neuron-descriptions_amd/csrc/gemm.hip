@@ -219,6 +219,90 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs g, int tiles_m,
       }
     }
   };
+  // Vectorised form: each wave transposes its accumulators through its own
+  // 8 KB slice of the (now idle) LDS, 32 rows x 64 cols at a time, and then
+  // moves whole 256-B row segments with 16-B per-lane loads/stores (residual
+  // read + output write are the HBM-bound part of the small-K 1x1 convs).
+  auto epilogue_vec = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
+    static_assert(WN == 64, "vector epilogue assumes 64-wide wave tiles");
+    float* stage = smem + wave * (32 * 64);
+    const int col4 = (lane & 15) * 4;
+    const int n = tile_n * BN + wn * WN + col4;
+    const bool n_ok = n < g.N;  // N % 4 == 0 guaranteed by the caller
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          stage[row * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+      // same-wave LDS ops complete in order: no barrier needed
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = tile_m * BM + wm * WM + i * 32 + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 64 + col4);
+        if (m < g.M && n_ok) {
+          v += bias4;
+          if constexpr (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD ||
+                        EPI == EPI_BIAS_SIGMUL) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(
+                g.aux + (long)m * g.ldaux + n);
+            if constexpr (EPI == EPI_BIAS_SIGMUL) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] = (1.f / (1.f + expf(-v[e]))) * a[e];
+            } else {
+              v += a;
+            }
+          }
+          if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if constexpr (EPI == EPI_BIAS_TANH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+          }
+          *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
+        }
+      }
+    }
+  };
+  const bool vec_ok =
+      (g.N % 4 == 0) && (g.ldc % 4 == 0) &&
+      ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
+      (g.bias == nullptr || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) &&
+      (g.aux == nullptr ||
+       ((g.ldaux % 4 == 0) && (reinterpret_cast<uintptr_t>(g.aux) & 15) == 0));
+  if (vec_ok) {
+    switch (g.epilogue) {
+      case EPI_BIAS_RELU:
+        epilogue_vec(std::integral_constant<int, EPI_BIAS_RELU>{});
+        break;
+      case EPI_BIAS_RES_RELU:
+        epilogue_vec(std::integral_constant<int, EPI_BIAS_RES_RELU>{});
+        break;
+      case EPI_BIAS_TANH:
+        epilogue_vec(std::integral_constant<int, EPI_BIAS_TANH>{});
+        break;
+      case EPI_BIAS_SIGMUL:
+        epilogue_vec(std::integral_constant<int, EPI_BIAS_SIGMUL>{});
+        break;
+      case EPI_BIAS_ADD:
+        epilogue_vec(std::integral_constant<int, EPI_BIAS_ADD>{});
+        break;
+      default:
+        epilogue_vec(std::integral_constant<int, EPI_BIAS>{});
+        break;
+    }
+    return;
+  }
   switch (g.epilogue) {
     case EPI_BIAS_RELU:
       epilogue(std::integral_constant<int, EPI_BIAS_RELU>{});
