@@ -165,6 +165,18 @@ int milan_describe(milan_ctx* ctx, const void* images, int image_dtype,
                    int32_t* out_len, void* workspace, size_t workspace_bytes,
                    milan_stream stream);
 
+/* Arithmetic mode of every dense contraction (convs, Linear, LSTM gates).
+ *   MILAN_PRECISION_F32       fp32-in / fp32-accumulate MFMA: bitwise an fmaf
+ *                             chain, the reference's precision (default).
+ *   MILAN_PRECISION_SPLIT_F16 operands carried as (hi,lo) f16 pairs (22
+ *                             significant bits), A.B = Ah.Bh + Ah.Bl + Al.Bh on
+ *                             the f16 matrix cores with fp32 accumulation:
+ *                             fp32-GEMM-class error at 1/3 of the f16 MFMA rate.
+ * Switchable at any time between calls (both weight packings are kept). */
+enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
+int milan_set_precision(milan_ctx* ctx, int precision);
+int milan_get_precision(const milan_ctx* ctx);
+
 /* Measurement hook (bench.py's roofline leg): while enabled, every launch of
  * the implicit-GEMM MFMA kernel is bracketed by HIP events on its launch
  * stream.  milan_profile_read synchronises the device and returns the summed
@@ -180,11 +192,13 @@ int milan_profile_read(double* gemm_ms, double* gemm_flops,
  * x (n,h,w,cin) NHWC with cin % 4 == 0; weight (cout,cin,kh,kw) OIHW as in the
  * reference state dict; bias (cout) or NULL; residual (n,ho,wo,cout) or NULL
  * (residual implies relu(conv + bias + residual)); y (n,ho,wo,cout).
+ * precision: MILAN_PRECISION_* (split mode converts x and the weights first).
  * Allocates temporaries and synchronises: not for the hot path. */
 int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       const float* weight_oihw, const float* bias, int cout,
                       int kh, int kw, int stride, int pad, int relu,
-                      const float* residual, float* y, milan_stream stream);
+                      const float* residual, float* y, int precision,
+                      milan_stream stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,56 @@ int dev_alloc(milan_ctx* c, void** p, size_t bytes) {
   return 0;
 }
 
+__global__ void absmax_kernel(const float* __restrict__ w, long n,
+                              unsigned int* __restrict__ out) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// Split-f16 copy of a packed [n][kp] fp32 weight into `dst` (same size);
+// d_max: device scratch word.  Returns 1/scale through ws_inv.
+static int split_weight_into(const float* w, int n, int kp, float* dst,
+                             float* ws_inv, unsigned int* d_max, hipStream_t s) {
+  MILAN_CHECK_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned int), s));
+  const long total = (long)n * kp;
+  long blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(absmax_kernel, dim3((int)blocks), dim3(256), 0, s, w, total,
+                     d_max);
+  unsigned int bits = 0;
+  MILAN_CHECK_HIP(hipMemcpyAsync(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost, s));
+  MILAN_CHECK_HIP(hipStreamSynchronize(s));
+  MILAN_CHECK_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned int), s));
+  float amax;
+  memcpy(&amax, &bits, sizeof(amax));
+  // scale = 2^e with max|w| * scale in [8192, 16384): hi never overflows f16
+  // and lo = O(2^-11 * hi) stays in the f16 normal range for all but tiny w.
+  float scale = 1.f;
+  if (amax > 0.f && amax < 3.0e38f) {
+    int e;
+    frexpf(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
+    int shift = 14 - e;
+    if (shift > 40) shift = 40;
+    if (shift < -40) shift = -40;
+    scale = ldexpf(1.f, shift);
+  }
+  MILAN_TRY(launch_f32_to_split(w, kp, dst, kp, n, kp, scale, s));
+  *ws_inv = 1.f / scale;
+  return 0;
+}
+
+int make_split_weight(milan_ctx* c, const float* w, int n, int kp, float** ws,
+                      float* ws_inv, hipStream_t s) {
+  if (kp % 32 != 0) { *ws = nullptr; *ws_inv = 1.f; return 0; }
+  unsigned int* d_max = reinterpret_cast<unsigned int*>(c->zero) + 32;  // scratch
+  MILAN_TRY(dev_alloc(c, (void**)ws, sizeof(float) * (size_t)n * kp));
+  return split_weight_into(w, n, kp, *ws, ws_inv, d_max, s);
+}
+
 }  // namespace milan
 
 using namespace milan;
@@ -194,13 +244,16 @@ int milan_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
 int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       const float* weight_oihw, const float* bias, int cout,
                       int kh, int kw, int stride, int pad, int relu,
-                      const float* residual, float* y, milan_stream stream) {
+                      const float* residual, float* y, int precision,
+                      milan_stream stream) {
   MILAN_REQUIRE(x && weight_oihw && y, MILAN_ERR_ARG, "conv2d: null argument");
+  MILAN_REQUIRE(precision == MILAN_PRECISION_F32 || cin % 32 == 0,
+                MILAN_ERR_SHAPE, "conv2d: split-f16 needs cin %% 32 == 0");
   MILAN_REQUIRE(cin % 4 == 0 && n > 0 && cout > 0, MILAN_ERR_SHAPE,
                 "conv2d: cin must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   const int K = kh * kw * cin, Kp = (K + 31) / 32 * 32;
-  float *wp = nullptr, *zero = nullptr;
+  float *wp = nullptr, *zero = nullptr, *xs = nullptr, *wsp = nullptr;
   MILAN_CHECK_HIP(hipMalloc((void**)&wp, sizeof(float) * (size_t)cout * Kp));
   MILAN_CHECK_HIP(hipMalloc((void**)&zero, 256));
   MILAN_CHECK_HIP(hipMemsetAsync(zero, 0, 256, s));
@@ -215,17 +268,45 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
     g.a_img_stride = (long)h * w * cin;
     g.epilogue = residual ? EPI_BIAS_RES_RELU : (relu ? EPI_BIAS_RELU : EPI_BIAS);
     g.zero = zero;
-    r = launch_gemm(g, s);
+    if (precision == MILAN_PRECISION_SPLIT_F16) {
+      const long rows = (long)n * h * w;
+      hipError_t e1 = hipMalloc((void**)&xs, sizeof(float) * (size_t)rows * cin);
+      hipError_t e2 = hipMalloc((void**)&wsp, sizeof(float) * (size_t)cout * Kp);
+      if (e1 != hipSuccess || e2 != hipSuccess) {
+        set_error("conv2d: out of memory");
+        r = (int)hipErrorOutOfMemory;
+      } else {
+        r = launch_f32_to_split(x, cin, xs, cin, rows, cin, 1.f, s);
+        if (r == 0)
+          r = split_weight_into(wp, cout, Kp, wsp, &g.acc_scale,
+                                reinterpret_cast<unsigned int*>(zero) + 32, s);
+        g.A = xs; g.W = wsp; g.a_split = 1;
+      }
+    }
+    if (r == 0) r = launch_gemm(g, s);
   }
   hipError_t e = hipStreamSynchronize(s);
   (void)hipFree(wp);
   (void)hipFree(zero);
+  if (xs) (void)hipFree(xs);
+  if (wsp) (void)hipFree(wsp);
   if (r == 0 && e != hipSuccess) {
     set_error("conv2d: %s", hipGetErrorString(e));
     r = (int)e;
   }
   return r;
 }
+
+int milan_set_precision(milan_ctx* c, int precision) {
+  MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
+  MILAN_REQUIRE(precision == MILAN_PRECISION_F32 ||
+                    precision == MILAN_PRECISION_SPLIT_F16,
+                MILAN_ERR_ARG, "unknown precision mode %d", precision);
+  c->precision = precision;
+  return 0;
+}
+
+int milan_get_precision(const milan_ctx* c) { return c ? c->precision : -1; }
 
 int milan_profile_enable(int enable) { return gemm_profile_enable(enable); }
 

@@ -65,9 +65,20 @@ struct GemmArgs {
   int epilogue;
   const float* zero;  // >= 64 B of zeros (device)
   int flop_k;         // algorithmic K for FLOP accounting (0 = K)
+  // split-f16 mode (see gemm.hip): A and W hold (hi,lo) f16 pairs
+  int a_split;        // 1: run the 3xf16 MFMA main loop
+  int out_split;      // 1: write C in split format (N % 8 == 0)
+  int aux_split;      // 1: aux is in split format
+  float acc_scale;    // accumulators are multiplied by this (1 / weight scale)
+  int out_mode;       // filled by the launcher (OUT_*)
 };
 
+enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2 };
+
 int launch_gemm(const GemmArgs& g, hipStream_t s);
+// rows x K fp32 (row stride ld_src) -> split format (row stride ld_dst), x scale
+int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
+                        long rows, int K, float scale, hipStream_t s);
 int gemm_profile_enable(int enable);
 int gemm_profile_read(double* ms, double* flops, long long* launches);
 
@@ -89,6 +100,8 @@ inline GemmArgs linear_args(const float* A, long lda, const float* W,
 // ---- packed weights ----------------------------------------------------------
 struct ConvW {
   float* w = nullptr;     // [Cout][Kp]
+  float* ws = nullptr;    // same, split-f16 format, scaled by 1/ws_inv
+  float ws_inv = 1.f;     // exact power of two
   float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
   int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;
   int cin_real = 0;  // channels before padding to a multiple of 4
@@ -99,6 +112,8 @@ struct Bottleneck {
 };
 struct LinearW {
   float* w = nullptr;  // [N][Kp]
+  float* ws = nullptr; // split-f16 copy (nullptr when K % 32 != 0)
+  float ws_inv = 1.f;
   float* b = nullptr;
   int n = 0, k = 0, kp = 0;
 };
@@ -135,6 +150,7 @@ struct milan_ctx {
   int device = 0;
   milan_dims d{};
   bool finalized = false;
+  int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16
   std::map<std::string, milan::Tensor> raw;  // named reference tensors
   // weight arena (library-owned, freed in milan_destroy)
   std::vector<void*> owned;
@@ -156,6 +172,10 @@ struct milan_ctx {
 
 namespace milan {
 int dev_alloc(milan_ctx* c, void** p, size_t bytes);
+// api.hip: split-f16 copy of a packed [n][kp] fp32 weight; picks a power-of-two
+// scale from max|w| (host sync) and returns its inverse.
+int make_split_weight(milan_ctx* c, const float* w, int n, int kp, float** ws,
+                      float* ws_inv, hipStream_t s);
 // encoder.hip
 int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
                     float* wp, hipStream_t s);

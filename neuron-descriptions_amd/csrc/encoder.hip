@@ -97,6 +97,9 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
                      out->cout, (int)w->shape[1], out->cin, out->kh, out->kw,
                      out->Kp, g, b, m, v, out->w, out->bias);
   MILAN_CHECK_HIP(hipGetLastError());
+  if (g && out->cin % 32 == 0)  // folded convs of the bottleneck stages
+    MILAN_TRY(make_split_weight(c, out->w, out->cout, out->Kp, &out->ws,
+                                &out->ws_inv, s));
   return 0;
 }
 
@@ -225,6 +228,69 @@ __global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, int n,
   }
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ inline void enc_split8(const float* v, f32x4_t* hi_out,
+                                  f32x4_t* lo_out) {
+  f16x8_t h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh;
+    l[e] = (_Float16)(x - (float)hh);
+  }
+  *hi_out = __builtin_bit_cast(f32x4_t, h);
+  *lo_out = __builtin_bit_cast(f32x4_t, l);
+}
+
+// Same, 8 channels per thread, output in split-f16 format (gemm.hip).
+__global__ void bn_relu_maxpool_split_kernel(const float* __restrict__ x, int n,
+                                             int H, int W, int C, int Ho, int Wo,
+                                             const float* __restrict__ scale,
+                                             const float* __restrict__ shift,
+                                             float* __restrict__ y) {
+  const int C8 = C >> 3;
+  const long total = (long)n * Ho * Wo * C8;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int c8 = idx % C8;
+    long t = idx / C8;
+    const int wo = t % Wo; t /= Wo;
+    const int ho = t % Ho;
+    const long img = t / Ho;
+    float sc[8], sh[8], best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = scale[c8 * 8 + e];
+      sh[e] = shift[c8 * 8 + e];
+      best[e] = -INFINITY;
+    }
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * 2 - 1 + dy;
+      if (hi < 0 || hi >= H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * 2 - 1 + dx;
+        if (wi < 0 || wi >= W) continue;
+        const float* p = x + ((img * H + hi) * W + wi) * C + c8 * 8;
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          best[e] = fmaxf(best[e], fmaxf(a[e] * sc[e] + sh[e], 0.f));
+          best[4 + e] = fmaxf(best[4 + e], fmaxf(b[e] * sc[4 + e] + sh[4 + e], 0.f));
+        }
+      }
+    }
+    f32x4_t hi4, lo4;
+    enc_split8(best, &hi4, &lo4);
+    float* d = y + idx * 8;
+    *reinterpret_cast<f32x4_t*>(d) = hi4;
+    *reinterpret_cast<f32x4_t*>(d + 4) = lo4;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // mask pyramid: bilinear resize (align_corners=False) + normalise + compact
 // ---------------------------------------------------------------------------
@@ -310,6 +376,7 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
 
 // features[img][col_off + c] = sum_p w[p] * tap[img][p][c]   (encoders.py:317)
 // grid (n_images, ceil(C/64)); 4 waves split the pixel list, lane = channel.
+template <bool SPLIT_IN>
 __global__ __launch_bounds__(256) void masked_pool_kernel(
     const float* __restrict__ tap, int P, int C, int level, Levels lv,
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
@@ -321,17 +388,28 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
   const int phase = threadIdx.x >> 6;
   const long base = (long)img * lv.per_image + lv.off[level];
   const int cnt = list_n[img * 5 + level];
-  const float* t = tap + (long)img * P * C + c;
+  // split format: channel c lives in group c/8 = 32 B [hi x8 | lo x8]
+  const long coff = SPLIT_IN ? (long)(c >> 3) * 8 : c;
+  const float* t = tap + (long)img * P * C + coff;
+  auto fetch = [&](int p) -> float {
+    if constexpr (SPLIT_IN) {
+      const _Float16* q =
+          reinterpret_cast<const _Float16*>(t + (long)p * C) + (c & 7);
+      return (float)q[0] + (float)q[8];
+    } else {
+      return t[(long)p * C];
+    }
+  };
   float acc0 = 0.f, acc1 = 0.f;
   if (c < C) {
     int i = phase;
     for (; i + 4 < cnt; i += 8) {
       const int p0 = list_idx[base + i], p1 = list_idx[base + i + 4];
       const float w0 = list_w[base + i], w1 = list_w[base + i + 4];
-      acc0 += w0 * t[(long)p0 * C];
-      acc1 += w1 * t[(long)p1 * C];
+      acc0 += w0 * fetch(p0);
+      acc1 += w1 * fetch(p1);
     }
-    if (i < cnt) acc0 += list_w[base + i] * t[(long)list_idx[base + i] * C];
+    if (i < cnt) acc0 += list_w[base + i] * fetch(list_idx[base + i]);
   }
   part[phase][threadIdx.x & 63] = acc0 + acc1;
   __syncthreads();
@@ -392,7 +470,8 @@ size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W) {
 
 static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
                           float* out, int epi, const float* aux,
-                          const float* zero, int* Ho, int* Wo) {
+                          const float* zero, int* Ho, int* Wo,
+                          bool split = false) {
   GemmArgs g{};
   *Ho = conv_out(H, cw.kh, cw.stride, cw.pad);
   *Wo = conv_out(W, cw.kw, cw.stride, cw.pad);
@@ -405,6 +484,10 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
   g.a_img_stride = (long)H * W * cw.cin;
   g.epilogue = epi; g.zero = zero;
   g.flop_k = cw.kh * cw.kw * cw.cin_real;
+  if (split) {
+    g.W = cw.ws; g.a_split = 1; g.out_split = 1; g.aux_split = aux != nullptr;
+    g.acc_scale = cw.ws_inv;
+  }
   return g;
 }
 
@@ -454,11 +537,22 @@ int encoder_run(milan_ctx* c, const void* images, int image_dtype,
     MILAN_CHECK_HIP(hipGetLastError());
   }
 
+  // split-f16 mode needs every bottleneck conv to have a split weight copy
+  bool split = c->precision == MILAN_PRECISION_SPLIT_F16 && wd % 8 == 0;
+  for (int li = 0; li < 4 && split; ++li)
+    for (const Bottleneck& b : c->blocks[li])
+      split = split && b.c1.ws && b.c2.ws && b.c3.ws && (!b.has_down || b.down.ws);
+
   auto pool = [&](const float* tap, int level, int C, int col_off) -> int {
     const int P = pl.lv.h[level] * pl.lv.w[level];
-    hipLaunchKernelGGL(masked_pool_kernel, dim3(n, (C + 63) / 64), dim3(256), 0,
-                       s, tap, P, C, level, pl.lv, pl.list_idx, pl.list_w,
-                       pl.list_n, features, F, col_off);
+    if (split && level > 0)
+      hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
+                         dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
+                         pl.list_w, pl.list_n, features, F, col_off);
+    else
+      hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(n, (C + 63) / 64),
+                         dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
+                         pl.list_w, pl.list_n, features, F, col_off);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   };
@@ -470,12 +564,17 @@ int encoder_run(milan_ctx* c, const void* images, int image_dtype,
                            c->zero, &ho, &wo);
     MILAN_TRY(launch_gemm(g, s));
     MILAN_TRY(pool(pl.raw, 0, wd, 0));
-    const long total = (long)n * pl.hp * pl.wp * (wd / 4);
+    const long total = (long)n * pl.hp * pl.wp * (wd / (split ? 8 : 4));
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, s,
-                       (const float4*)pl.raw, n, pl.h1, pl.w1, wd / 4, pl.hp,
-                       pl.wp, (const float4*)c->bn1_scale,
-                       (const float4*)c->bn1_shift, (float4*)pl.x0);
+    if (split)
+      hipLaunchKernelGGL(bn_relu_maxpool_split_kernel, dim3(blocks), dim3(256), 0,
+                         s, pl.raw, n, pl.h1, pl.w1, wd, pl.hp, pl.wp,
+                         c->bn1_scale, c->bn1_shift, pl.x0);
+    else
+      hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, s,
+                         (const float4*)pl.raw, n, pl.h1, pl.w1, wd / 4, pl.hp,
+                         pl.wp, (const float4*)c->bn1_scale,
+                         (const float4*)c->bn1_shift, (float4*)pl.x0);
     MILAN_CHECK_HIP(hipGetLastError());
   }
 
@@ -486,21 +585,21 @@ int encoder_run(milan_ctx* c, const void* images, int image_dtype,
     for (const Bottleneck& b : c->blocks[li]) {
       int h1, w1, h2, w2, h3, w3;
       GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
-                              c->zero, &h1, &w1);
+                              c->zero, &h1, &w1, split);
       MILAN_TRY(launch_gemm(g1, s));
       GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU,
-                              nullptr, c->zero, &h2, &w2);
+                              nullptr, c->zero, &h2, &w2, split);
       MILAN_TRY(launch_gemm(g2, s));
       const float* identity = x;
       if (b.has_down) {
         int hd, wdn;
         GemmArgs gd = conv_args(b.down, x, n, h, w, pl.ds, EPI_BIAS, nullptr,
-                                c->zero, &hd, &wdn);
+                                c->zero, &hd, &wdn, split);
         MILAN_TRY(launch_gemm(gd, s));
         identity = pl.ds;
       }
       GemmArgs g3 = conv_args(b.c3, pl.t2, n, h2, w2, y, EPI_BIAS_RES_RELU,
-                              identity, c->zero, &h3, &w3);
+                              identity, c->zero, &h3, &w3, split);
       MILAN_TRY(launch_gemm(g3, s));
       float* tmp = x; x = y; y = tmp;
       h = h3; w = w3;

@@ -1,29 +1,45 @@
-// Implicit-GEMM convolution / linear layer on the gfx950 fp32 matrix cores.
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
 //
-// One kernel serves every dense contraction on the MILAN path: the ResNet
-// trunk's convolutions (torchvision resnet101, reference call site
+// One kernel family serves every dense contraction on the MILAN path: the
+// ResNet trunk's convolutions (torchvision resnet101, reference call site
 // src/milan/encoders.py:298) and every nn.Linear / LSTM gate product of the
 // decoder and LM (src/milan/decoders.py:304-323,576-634; src/milan/lms.py:
-// 47-56).  Arithmetic is v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
-// bit-for-bit an fmaf chain over K (MI355X guide §3), so results match the
-// reference's fp32 to summation-order round-off.
+// 47-56).  Two arithmetic modes share the tiling, the loader and the epilogue:
+//
+//   F32   v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit an fmaf
+//         chain over K (MI355X guide section 3).  157 TFLOP/s roof.  Differs
+//         from the reference's fp32 only by summation order.
+//   SPLIT v_mfma_f32_32x32x16_f16 on operands stored as (hi, lo) f16 pairs:
+//         x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 significant bits).
+//         A.B ~= Ah.Bh + (Ah.Bl + Al.Bh), three f16 MFMAs with exact products
+//         and f32 accumulation (the 2^-22-relative Al.Bl term is dropped); the
+//         cross terms get their own accumulator so they are not rounded into
+//         the large sum one at a time.  Error is of fp32-GEMM class (measured
+//         in tests/test_gpu_parity.py), rate is 1/3 of the f16 MFMA roof =
+//         833 TFLOP/s-equivalent, 5.3x the F32 mode.
+//
+// Split storage format ("f16x2-interleaved"): a row of C channels occupies the
+// same 4*C bytes as fp32; every 8 channels form a 32-byte group [hi x8 | lo x8].
+// A 16-byte chunk is therefore 4 fp32 channels in F32 mode or one half-group
+// in SPLIT mode, the byte addressing is identical, and the HBM->LDS loader
+// below does not know which mode it is feeding.
 //
 // Tiling (wave64, 4 waves / 256 threads per workgroup):
-//   block tile BM x BN, k-tile 32 floats; each wave owns WM x WN made of
-//   32x32 MFMA tiles.  A (implicit im2col rows, NHWC so a (kh,kw) tap is a
-//   contiguous Cin run) and W ([N][Kp], K contiguous) are streamed
+//   block tile BM x BN, k-tile = 32 channel slots (128 B per row); each wave
+//   owns 64 x 64 = 2 x 2 MFMA 32x32 tiles.  A (implicit im2col rows, NHWC so
+//   a (kh,kw) tap is a contiguous Cin run) and W ([N][Kp], K contiguous) go
 //   HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR staging),
-//   double buffered.  LDS rows are 128 B; the 16-B chunk p of row r holds
-//   k-chunk p ^ ((r>>1)&7) (swizzle applied on the per-lane SOURCE address,
-//   undone on the ds_read_b128), which makes both the lane-linear DMA write
-//   and the row-per-lane fragment read bank-conflict free.
-//   A fragment read: lane l takes 4 consecutive k of row (l&31); lanes 0-31
-//   take k-chunk 2g, lanes 32-63 chunk 2g+1, so one ds_read_b128 per operand
-//   feeds four K=2 MFMAs.
-//   Workgroup -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous
-//   range of tiles (n fastest), so the blocks sharing an A row-panel hit the
-//   same 4 MiB L2.
+//   double buffered.  The 16-B chunk p of LDS row r holds k-chunk
+//   p ^ ((r>>1)&7): the swizzle is applied on the per-lane SOURCE address
+//   (the DMA destination is lane-linear) and undone on the ds_read_b128, which
+//   makes both the DMA write and the row-per-lane fragment read conflict free.
+//   Workgroup -> tile mapping is XCD-aware: each of the 8 XCDs walks a
+//   contiguous range of tiles (n fastest), so blocks sharing an A row panel
+//   share one 4 MiB L2.
+//   Epilogue: accumulators are transposed through the (idle) LDS so that HBM
+//   sees 16-byte per-lane accesses covering whole 256-B row segments.
 #include "common.h"
+
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -32,6 +48,7 @@ namespace milan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -41,13 +58,38 @@ struct RowInfo {
   int hi0, wi0;
 };
 
-template <int BM, int BN, int WM, int WN, bool CIN32>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs g, int tiles_m,
-                                                         int tiles_n) {
+__device__ inline f16x8 as_f16x8(f32x4 v) {
+  return __builtin_bit_cast(f16x8, v);
+}
+
+// 8 fp32 -> (hi, lo) f16x8 pair.  hi saturates instead of overflowing to inf.
+__device__ inline void split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh;
+    l[e] = (_Float16)(x - (float)hh);
+  }
+  *hi_out = __builtin_bit_cast(f32x4, h);
+  *lo_out = __builtin_bit_cast(f32x4, l);
+}
+
+__device__ inline void join8(f32x4 hi, f32x4 lo, float* v) {
+  const f16x8 h = as_f16x8(hi), l = as_f16x8(lo);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)h[e] + (float)l[e];
+}
+
+template <int BM, int BN, int WM, int WN, bool CIN32, bool SPLIT>
+__global__ __launch_bounds__(256) void igemm_kernel(GemmArgs g, int tiles_m,
+                                                     int tiles_n) {
   constexpr int BK = 32;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(WN == 64 && WM == 64, "epilogues assume 64x64 wave tiles");
   constexpr int A_ITERS = BM / 32, B_ITERS = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM*32]
@@ -132,15 +174,18 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs g, int tiles_m,
   };
 
   f32x16 acc[TM][TN];
+  f32x16 accx[SPLIT ? TM : 1][SPLIT ? TN : 1];  // cross terms (SPLIT only)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (SPLIT) accx[i][j][r] = 0.f;
+      }
 
   const int nk = g.Kp / BK;
-  // fragment read offsets (floats) within a buffer, for g = 0
   const int frow = lane & 31, fhalf = lane >> 5;
   int aoff[TM], boff[TN], aswz[TM], bswz[TN];
 #pragma unroll
@@ -165,88 +210,104 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs g, int tiles_m,
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const float* Ab = As + cur * (BM * BK);
     const float* Bb = Bs + cur * (BN * BK);
+    if constexpr (!SPLIT) {
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int chunk = 2 * gq + fhalf;
-      f32x4 a[TM], b[TN];
+      for (int gq = 0; gq < 4; ++gq) {
+        const int chunk = 2 * gq + fhalf;
+        f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(Ab + aoff[i] +
-                                               ((chunk ^ aswz[i]) << 2));
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const f32x4*>(Ab + aoff[i] +
+                                                 ((chunk ^ aswz[i]) << 2));
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] +
-                                               ((chunk ^ bswz[j]) << 2));
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] +
+                                                 ((chunk ^ bswz[j]) << 2));
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                  a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // two K=16 slabs per k-tile; lanes 0-31 feed channels 0-7 of the slab,
+      // lanes 32-63 channels 8-15: group q = 2*slab + half, hi chunk 2q, lo 2q+1
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int chi = 2 * (2 * sl + fhalf), clo = chi + 1;
+        f32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = *reinterpret_cast<const f32x4*>(Ab + aoff[i] +
+                                                  ((chi ^ aswz[i]) << 2));
+          al[i] = *reinterpret_cast<const f32x4*>(Ab + aoff[i] +
+                                                  ((clo ^ aswz[i]) << 2));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] +
+                                                  ((chi ^ bswz[j]) << 2));
+          bl[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] +
+                                                  ((clo ^ bswz[j]) << 2));
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                as_f16x8(ah[i]), as_f16x8(bh[j]), acc[i][j], 0, 0, 0);
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                as_f16x8(ah[i]), as_f16x8(bl[j]), accx[i][j], 0, 0, 0);
+            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                as_f16x8(al[i]), as_f16x8(bh[j]), accx[i][j], 0, 0, 0);
+          }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = (acc[i][j] + accx[i][j]) * g.acc_scale;
+  }
 
-  // ---- epilogue ---------------------------------------------------------------
+  // ---- epilogues ----------------------------------------------------------------
   // D layout (32x32): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  auto epilogue = [&](auto epi_tag) {
-    constexpr int EPI = decltype(epi_tag)::value;
+  constexpr int SROW = 68;  // staging row stride (floats): 64 + 4 de-conflicts
+  float* stage_out = smem + wave * (32 * SROW);
+  auto to_stage = [&](int i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = tile_n * BN + wn * WN + j * 32 + (lane & 31);
-      if (n >= g.N) continue;
-      const float bias = g.bias ? g.bias[n] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mbase = tile_m * BM + wm * WM + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          if (m >= g.M) continue;
-          float v = acc[i][j][r] + bias;
-          if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-          if constexpr (EPI == EPI_BIAS_RES_RELU)
-            v = fmaxf(v + g.aux[(long)m * g.ldaux + n], 0.f);
-          if constexpr (EPI == EPI_BIAS_ADD) v = v + g.aux[(long)m * g.ldaux + n];
-          if constexpr (EPI == EPI_BIAS_TANH) v = tanhf(v);
-          if constexpr (EPI == EPI_BIAS_SIGMUL)
-            v = (1.f / (1.f + expf(-v))) * g.aux[(long)m * g.ldaux + n];
-          g.C[(long)m * g.ldc + n] = v;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        stage_out[row * SROW + j * 32 + (lane & 31)] = acc[i][j][r];
       }
-    }
+    // same-wave LDS ops complete in order: no barrier needed
   };
-  // Vectorised form: each wave transposes its accumulators through its own
-  // 8 KB slice of the (now idle) LDS, 32 rows x 64 cols at a time, and then
-  // moves whole 256-B row segments with 16-B per-lane loads/stores (residual
-  // read + output write are the HBM-bound part of the small-K 1x1 convs).
-  auto epilogue_vec = [&](auto epi_tag) {
+
+  // (1) fp32 out, fp32 aux, float4 per lane.
+  auto epilogue_vec4 = [&](auto epi_tag) {
     constexpr int EPI = decltype(epi_tag)::value;
-    static_assert(WN == 64, "vector epilogue assumes 64-wide wave tiles");
-    float* stage = smem + wave * (32 * 64);
     const int col4 = (lane & 15) * 4;
     const int n = tile_n * BN + wn * WN + col4;
-    const bool n_ok = n < g.N;  // N % 4 == 0 guaranteed by the caller
+    const bool n_ok = n < g.N;  // N % 4 == 0 checked by the launcher
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          stage[row * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
-        }
-      // same-wave LDS ops complete in order: no barrier needed
+      to_stage(i);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = it * 4 + (lane >> 4);
         const int m = tile_m * BM + wm * WM + i * 32 + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 64 + col4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage_out + row * SROW + col4);
         if (m < g.M && n_ok) {
           v += bias4;
           if constexpr (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD ||
@@ -274,62 +335,162 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs g, int tiles_m,
       }
     }
   };
-  const bool vec_ok =
-      (g.N % 4 == 0) && (g.ldc % 4 == 0) &&
-      ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
-      (g.bias == nullptr || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) &&
-      (g.aux == nullptr ||
-       ((g.ldaux % 4 == 0) && (reinterpret_cast<uintptr_t>(g.aux) & 15) == 0));
-  if (vec_ok) {
-    switch (g.epilogue) {
-      case EPI_BIAS_RELU:
-        epilogue_vec(std::integral_constant<int, EPI_BIAS_RELU>{});
-        break;
-      case EPI_BIAS_RES_RELU:
-        epilogue_vec(std::integral_constant<int, EPI_BIAS_RES_RELU>{});
-        break;
-      case EPI_BIAS_TANH:
-        epilogue_vec(std::integral_constant<int, EPI_BIAS_TANH>{});
-        break;
-      case EPI_BIAS_SIGMUL:
-        epilogue_vec(std::integral_constant<int, EPI_BIAS_SIGMUL>{});
-        break;
-      case EPI_BIAS_ADD:
-        epilogue_vec(std::integral_constant<int, EPI_BIAS_ADD>{});
-        break;
-      default:
-        epilogue_vec(std::integral_constant<int, EPI_BIAS>{});
-        break;
+
+  // (2) split-format out (and aux): 8 channels = one 32-B group per lane.
+  auto epilogue_split8 = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
+    const int col8 = (lane & 7) * 8;
+    const int n = tile_n * BN + wn * WN + col8;
+    const bool n_ok = n < g.N;  // N % 8 == 0 checked by the launcher
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n_ok) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
-    return;
-  }
-  switch (g.epilogue) {
-    case EPI_BIAS_RELU:
-      epilogue(std::integral_constant<int, EPI_BIAS_RELU>{});
-      break;
-    case EPI_BIAS_RES_RELU:
-      epilogue(std::integral_constant<int, EPI_BIAS_RES_RELU>{});
-      break;
-    case EPI_BIAS_TANH:
-      epilogue(std::integral_constant<int, EPI_BIAS_TANH>{});
-      break;
-    case EPI_BIAS_SIGMUL:
-      epilogue(std::integral_constant<int, EPI_BIAS_SIGMUL>{});
-      break;
-    case EPI_BIAS_ADD:
-      epilogue(std::integral_constant<int, EPI_BIAS_ADD>{});
-      break;
-    default:
-      epilogue(std::integral_constant<int, EPI_BIAS>{});
-      break;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      to_stage(i);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int m = tile_m * BM + wm * WM + i * 32 + row;
+        const f32x4 v0 =
+            *reinterpret_cast<const f32x4*>(stage_out + row * SROW + col8);
+        const f32x4 v1 =
+            *reinterpret_cast<const f32x4*>(stage_out + row * SROW + col8 + 4);
+        if (m < g.M && n_ok) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = v0[e] + bias8[e];
+            v[4 + e] = v1[e] + bias8[4 + e];
+          }
+          if constexpr (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD) {
+            const float* ap = g.aux + (long)m * g.ldaux + n;
+            float a[8];
+            join8(*reinterpret_cast<const f32x4*>(ap),
+                  *reinterpret_cast<const f32x4*>(ap + 4), a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+          }
+          if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          f32x4 hi, lo;
+          split8(v, &hi, &lo);
+          float* cp = g.C + (long)m * g.ldc + n;
+          *reinterpret_cast<f32x4*>(cp) = hi;
+          *reinterpret_cast<f32x4*>(cp + 4) = lo;
+        }
+      }
+    }
+  };
+
+  // (3) scalar fallback (unaligned fp32 outputs of odd-sized test models).
+  auto epilogue_scalar = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = tile_n * BN + wn * WN + j * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mbase = tile_m * BM + wm * WM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m >= g.M) continue;
+          float v = acc[i][j][r] + bias;
+          if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+          if constexpr (EPI == EPI_BIAS_RES_RELU)
+            v = fmaxf(v + g.aux[(long)m * g.ldaux + n], 0.f);
+          if constexpr (EPI == EPI_BIAS_ADD) v = v + g.aux[(long)m * g.ldaux + n];
+          if constexpr (EPI == EPI_BIAS_TANH) v = tanhf(v);
+          if constexpr (EPI == EPI_BIAS_SIGMUL)
+            v = (1.f / (1.f + expf(-v))) * g.aux[(long)m * g.ldaux + n];
+          g.C[(long)m * g.ldc + n] = v;
+        }
+      }
+    }
+  };
+
+  auto dispatch = [&](auto&& fn) {
+    switch (g.epilogue) {
+      case EPI_BIAS_RELU: fn(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
+      case EPI_BIAS_RES_RELU: fn(std::integral_constant<int, EPI_BIAS_RES_RELU>{}); break;
+      case EPI_BIAS_TANH: fn(std::integral_constant<int, EPI_BIAS_TANH>{}); break;
+      case EPI_BIAS_SIGMUL: fn(std::integral_constant<int, EPI_BIAS_SIGMUL>{}); break;
+      case EPI_BIAS_ADD: fn(std::integral_constant<int, EPI_BIAS_ADD>{}); break;
+      default: fn(std::integral_constant<int, EPI_BIAS>{}); break;
+    }
+  };
+  if (g.out_mode == OUT_SPLIT8) {
+    // only the conv epilogues exist in split form
+    switch (g.epilogue) {
+      case EPI_BIAS_RELU: epilogue_split8(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
+      case EPI_BIAS_RES_RELU: epilogue_split8(std::integral_constant<int, EPI_BIAS_RES_RELU>{}); break;
+      case EPI_BIAS_ADD: epilogue_split8(std::integral_constant<int, EPI_BIAS_ADD>{}); break;
+      default: epilogue_split8(std::integral_constant<int, EPI_BIAS>{}); break;
+    }
+  } else if (g.out_mode == OUT_VEC4) {
+    dispatch(epilogue_vec4);
+  } else {
+    dispatch(epilogue_scalar);
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool CIN32>
+// ---------------------------------------------------------------------------
+// fp32 <-> split-format conversion of a row-major matrix (rows x K, K % 8 == 0)
+// ---------------------------------------------------------------------------
+__global__ void f32_to_split_kernel(const float* __restrict__ src, long lds_,
+                                    float* __restrict__ dst, long ldd, long rows,
+                                    int K, float scale) {
+  const int g8 = K >> 3;
+  const long total = rows * g8;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / g8;
+    const int q = idx - r * g8;
+    const float* s = src + r * lds_ + q * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(s + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e] * scale; v[4 + e] = b[e] * scale; }
+    f32x4 hi, lo;
+    split8(v, &hi, &lo);
+    float* d = dst + r * ldd + q * 8;
+    *reinterpret_cast<f32x4*>(d) = hi;
+    *reinterpret_cast<f32x4*>(d + 4) = lo;
+  }
+}
+
+int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
+                        long rows, int K, float scale, hipStream_t s) {
+  MILAN_REQUIRE(K % 8 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, MILAN_ERR_SHAPE,
+                "f32_to_split: K=%d must be a multiple of 8", K);
+  const long total = rows * (K >> 3);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(f32_to_split_kernel, dim3((int)blocks), dim3(256), 0, s, src,
+                     ld_src, dst, ld_dst, rows, K, scale);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool CIN32, bool SPLIT>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const size_t lds = size_t(2) * (BM + BN) * 32 * sizeof(float);
-  auto kern = igemm_f32_kernel<BM, BN, WM, WN, CIN32>;
+  auto kern = igemm_kernel<BM, BN, WM, WN, CIN32, SPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
     MILAN_CHECK_HIP(hipFuncSetAttribute(
@@ -375,23 +536,56 @@ int gemm_profile_read(double* ms, double* flops, long long* launches) {
   return 0;
 }
 
-static int launch_gemm_impl(const GemmArgs& g, hipStream_t s) {
+static bool aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   const bool cin32 = (g.Cin % 32 == 0);
-  if (g.N <= 64) {
-    return cin32 ? launch_cfg<256, 64, 64, 64, true>(g, s)
-                 : launch_cfg<256, 64, 64, 64, false>(g, s);
+  // pick the epilogue form
+  if (g.out_split || g.aux_split) {
+    MILAN_REQUIRE(g.out_split && g.N % 8 == 0 && g.ldc % 8 == 0 && aligned16(g.C) &&
+                      (g.bias == nullptr || aligned16(g.bias)) &&
+                      (g.aux == nullptr ||
+                       (g.aux_split && g.ldaux % 8 == 0 && aligned16(g.aux))) &&
+                      (g.epilogue == EPI_BIAS || g.epilogue == EPI_BIAS_RELU ||
+                       g.epilogue == EPI_BIAS_RES_RELU ||
+                       g.epilogue == EPI_BIAS_ADD),
+                  MILAN_ERR_SHAPE,
+                  "gemm: unsupported split-format epilogue (N=%d ldc=%d epi=%d)",
+                  g.N, g.ldc, g.epilogue);
+    g.out_mode = OUT_SPLIT8;
+  } else {
+    const bool vec_ok = (g.N % 4 == 0) && (g.ldc % 4 == 0) && aligned16(g.C) &&
+                        (g.bias == nullptr || aligned16(g.bias)) &&
+                        (g.aux == nullptr ||
+                         ((g.ldaux % 4 == 0) && aligned16(g.aux)));
+    g.out_mode = vec_ok ? OUT_VEC4 : OUT_SCALAR;
   }
-  return cin32 ? launch_cfg<128, 128, 64, 64, true>(g, s)
-               : launch_cfg<128, 128, 64, 64, false>(g, s);
+  if (g.a_split) {
+    MILAN_REQUIRE(cin32, MILAN_ERR_SHAPE,
+                  "gemm: split-f16 operands need Cin %% 32 == 0 (Cin=%d)", g.Cin);
+    if (g.acc_scale == 0.f) g.acc_scale = 1.f;
+    if (g.N <= 64) return launch_cfg<256, 64, 64, 64, true, true>(g, s);
+    return launch_cfg<128, 128, 64, 64, true, true>(g, s);
+  }
+  if (g.N <= 64) {
+    return cin32 ? launch_cfg<256, 64, 64, 64, true, false>(g, s)
+                 : launch_cfg<256, 64, 64, 64, false, false>(g, s);
+  }
+  return cin32 ? launch_cfg<128, 128, 64, 64, true, false>(g, s)
+               : launch_cfg<128, 128, 64, 64, false, false>(g, s);
 }
 
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
   MILAN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, MILAN_ERR_SHAPE,
                 "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
   MILAN_REQUIRE(g.Cin % 4 == 0 && g.a_pix_stride % 4 == 0 &&
-                    g.a_img_stride % 4 == 0 && g.Kp % 32 == 0,
+                    g.a_img_stride % 4 == 0 && g.Kp % 32 == 0 && aligned16(g.A) &&
+                    aligned16(g.W),
                 MILAN_ERR_SHAPE,
-                "gemm: Cin=%d / strides must be multiples of 4 floats", g.Cin);
+                "gemm: Cin=%d / strides must be multiples of 4 floats and "
+                "operands 16-byte aligned", g.Cin);
   if (!g_prof.on) return launch_gemm_impl(g, s);
   if (g_prof.used == g_prof.ev.size()) {
     hipEvent_t a, b;

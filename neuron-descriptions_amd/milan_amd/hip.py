@@ -18,6 +18,8 @@ import torch
 LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so'
 
 GREEDY, BEAM, RERANK = 0, 2, 3  # MILAN_GREEDY / MILAN_BEAM / MILAN_RERANK
+PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
+PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16}
 DTYPE_U8, DTYPE_F32 = 0, 1
 
 ERR_ARG, ERR_SHAPE, ERR_STATE, ERR_WORKSPACE, ERR_NO_LM = -1, -2, -3, -4, -5
@@ -79,6 +81,8 @@ SIGNATURES = {
         _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P,
         _P, _P, _P, _P, _P, _P, _SZ, _P
     ]),
+    'milan_set_precision': (_I, [_P, _I]),
+    'milan_get_precision': (_I, [_P]),
     'milan_profile_enable': (_I, [_I]),
     'milan_profile_read': (_I, [
         ctypes.POINTER(ctypes.c_double),
@@ -86,7 +90,8 @@ SIGNATURES = {
         ctypes.POINTER(ctypes.c_longlong)
     ]),
     'milan_conv2d_nhwc':
-        (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+        (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I,
+              _P]),
 }
 
 _lib = None
@@ -181,6 +186,22 @@ class Context:
                                                 _stream(self.device)))
             del keep
         self._ws: Optional[torch.Tensor] = None
+        default = os.environ.get('MILAN_PRECISION')
+        if default:
+            self.set_precision(default)
+
+    def set_precision(self, precision) -> None:
+        """'f32' (exact fp32 MFMA, default) or 'split_f16' (3xf16 MFMA)."""
+        if isinstance(precision, str):
+            if precision not in PRECISIONS:
+                raise ValueError(f'unknown precision: {precision}')
+            precision = PRECISIONS[precision]
+        _check(self.lib.milan_set_precision(self._h, int(precision)))
+
+    @property
+    def precision(self) -> str:
+        code = self.lib.milan_get_precision(self._h)
+        return {v: k for k, v in PRECISIONS.items()}[code]
 
     def close(self) -> None:
         if getattr(self, '_h', None) is not None and self._h:
@@ -407,7 +428,8 @@ def conv2d_nhwc(x: torch.Tensor,
                 stride: int = 1,
                 padding: int = 0,
                 relu: bool = False,
-                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                residual: Optional[torch.Tensor] = None,
+                precision: str = 'f32') -> torch.Tensor:
     """Test hook for the implicit-GEMM kernel (milan_conv2d_nhwc)."""
     lib = load_library()
     device = require_device(x.device)
@@ -423,7 +445,8 @@ def conv2d_nhwc(x: torch.Tensor,
             lib.milan_conv2d_nhwc(x.data_ptr(), n, h, w, cin,
                                   weight.data_ptr(), _ptr(bias), cout, kh, kw,
                                   stride, padding, int(relu), _ptr(residual),
-                                  y.data_ptr(), _stream(device)))
+                                  y.data_ptr(), PRECISIONS[precision],
+                                  _stream(device)))
     return y
 
 

@@ -352,3 +352,99 @@ def test_describe_end_to_end_matches_oracle(dev, strategy):
             assert torch.equal(out['tokens'].cpu()[:, :tp], want['tokens'])
             close(out['scores'], want['scores'], 1e-4, 3e-3)
     ctx.close()
+
+
+# --------------------------------------------------------------------------
+# split-f16 precision mode (3 x f16 MFMA on (hi,lo) pairs)
+# --------------------------------------------------------------------------
+SPLIT_CASES = [c for c in CONV_CASES if c[3] % 32 == 0]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_split_f16_conv_error_is_fp32_class(dev, case):
+    """Against an fp64 reference the split kernel's error must be of the same
+    class as the exact-fp32 MFMA kernel's own rounding error."""
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(7 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k))**.5
+    b = torch.randn(cout, generator=g)
+    want = F.conv2d(x.double(), wt.double(), b.double(), stride=stride,
+                    padding=pad)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    errs = {}
+    for prec in ('f32', 'split_f16'):
+        got = hip.conv2d_nhwc(x_nhwc, wt.to(dev), b.to(dev), stride, pad,
+                              precision=prec).permute(0, 3, 1, 2).cpu().double()
+        errs[prec] = float((got - want).abs().max())
+    scale = float(want.abs().max())
+    assert errs['split_f16'] <= max(4 * errs['f32'], 2e-6 * scale), errs
+    assert errs['split_f16'] <= 1e-5 * scale, errs
+
+
+def test_split_f16_handles_tiny_and_large_values(dev):
+    """Operand magnitudes far from 1: weights are rescaled by a power of two,
+    activations saturate instead of overflowing to inf."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    x[0] *= 1e-3
+    x[1] *= 300.0
+    for wmag in (1e-4, 1.0, 50.0):
+        wt = torch.randn(64, 64, 1, 1, generator=g) * wmag
+        want = F.conv2d(x.double(), wt.double())
+        got = hip.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev),
+                              wt.to(dev), precision='split_f16')
+        got = got.permute(0, 3, 1, 2).cpu().double()
+        # image 0 (|x| ~ 1e-3): the lo halves fall into the f16 subnormal range,
+        # so the error floor is absolute (~3e-8 per element) and the relative
+        # error degrades gracefully; image 1 (|x| ~ 300) keeps full accuracy
+        # (DESIGN.md section 4).
+        for i, bound in ((0, 1e-4), (1, 5e-6)):
+            rel = float((got[i] - want[i]).abs().max() / want[i].abs().max())
+            assert rel < bound, (wmag, i, rel)
+
+
+@pytest.mark.parametrize('tag', ['slim224', 'r50_64', 'full224'])
+def test_split_f16_encoder_matches_reference_golden(dev, goldens, golden_meta,
+                                                    tag):
+    m = golden_meta[f'g1_{tag}']
+    if m['width'] % 8:
+        pytest.skip('split mode needs width % 8 == 0')
+    ctx, _ = _encoder_ctx(m, dev)
+    ctx.set_precision('split_f16')
+    assert ctx.precision == 'split_f16'
+    images_u8, _ = synthetic.exemplars(1, k=m['m'], size=m['size'],
+                                       seed=m['image_seed'], zero_every=0)
+    got = ctx.encode(images_u8[0], goldens[f'g1_{tag}_masks_u8'][0])
+    want = goldens[f'g1_{tag}_features']
+    close(got, want, rtol=2e-3, atol=2e-4)
+    assert got[1].eq(0).all()
+    ctx.set_precision('f32')
+    got32 = ctx.encode(images_u8[0], goldens[f'g1_{tag}_masks_u8'][0])
+    # report how the two modes compare against the reference
+    e32 = float((got32.cpu() - want).abs().max())
+    esp = float((got.cpu() - want).abs().max())
+    print(f'{tag}: max|err| f32={e32:.3g} split_f16={esp:.3g} '
+          f'(feature max {float(want.abs().max()):.3g})')
+    ctx.close()
+
+
+def test_split_f16_describe_end_to_end(dev):
+    nv, width, k, n, size = 60, 32, 5, 6, 96
+    blocks = synthetic.RESNET_BLOCKS['resnet50']
+    sd = synthetic.milan_state_dict(nv + 4, config='resnet50', seed=12,
+                                    width=width, hidden_size=64,
+                                    embedding_size=32, lm_hidden_size=64,
+                                    lm_embedding_size=32)
+    ctx = hip.Context(hip.make_dims(sd, nv, blocks=blocks), sd, dev)
+    ctx.set_precision('split_f16')
+    images, masks = synthetic.exemplars(n, k=k, size=size, seed=6, zero_every=7)
+    feats = O.encode(O.byte_to_float(images), masks.float(), sd, blocks=blocks)
+    want = O.forward(feats, sd, nv, 'greedy', length=10, mi=False)
+    out = ctx.describe(images, masks, hip.GREEDY, 10, 1, False, 0.2,
+                       want_full=True, want_features=True)
+    close(out['features'], feats, 2e-3, 2e-4)
+    top2 = want['predictions'].topk(2, dim=-1).values
+    assert_tokens_match(out['tokens'], want['tokens'],
+                        top2[..., 0] - top2[..., 1])
+    ctx.close()

@@ -1,0 +1,68 @@
+"""Per-layer GEMM throughput from a rocprofv3 rocpd database of bench.py.
+
+usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3]
+Maps the igemm dispatches of one hot-path pass onto the ResNet-101 layer list
+(launch order is deterministic) and prints time / algorithmic TFLOP/s per
+layer group, then the decoder+LM GEMM total.
+"""
+import re
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
+    passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    rows = db.execute(
+        "select name, start, end-start, grid_x from kernels where name like "
+        "'%igemm%' order by start").fetchall()
+    per = len(rows) // passes
+    rows = rows[per * (passes - 1):]
+    layers = []
+
+    def conv(name, h, cin, cout, k, s):
+        ho = (h + 2 * (k // 2) - k) // s + 1
+        m = n * ho * ho
+        layers.append((name, m, cout, k * k * cin, 2 * m * cout * k * k * cin))
+        return ho
+
+    conv('stem', 224, 3, 64, 7, 2)
+    h, inp = 56, 64
+    for li, nb in enumerate((3, 4, 23, 3)):
+        pl = 64 * 2**li
+        for bi in range(nb):
+            s = 2 if (bi == 0 and li > 0) else 1
+            conv(f'l{li+1}.{bi}.c1', h, inp, pl, 1, 1)
+            h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
+            if bi == 0:
+                conv(f'l{li+1}.{bi}.ds', h, inp, pl * 4, 1, s)
+            conv(f'l{li+1}.{bi}.c3', h2, pl, pl * 4, 1, 1)
+            h, inp = h2, pl * 4
+    agg, tot_t, tot_f = {}, 0, 0
+    for (name, m, nn, k, fl), (_, _, du, _) in zip(layers, rows):
+        key = name if '.0.' in name or name == 'stem' else re.sub(
+            r'\.\d+\.', '.x.', name)
+        a = agg.setdefault(key, [0, 0, 0, m, nn, k])
+        a[0] += fl
+        a[1] += du
+        a[2] += 1
+        tot_t += du
+        tot_f += fl
+    print(f'encoder GEMMs: {tot_f/1e12:.2f} TFLOP in {tot_t/1e6:.1f} ms = '
+          f'{tot_f/tot_t/1e3:.1f} TF/s')
+    for k, (fl, du, c, m, nn, kk) in agg.items():
+        print(f'{k:9s} x{c:2d} M={m:8d} N={nn:5d} K={kk:5d} {du/1e6:8.2f} ms '
+              f'{fl/du/1e3:6.1f} TF/s {100*du/tot_t:5.1f}%')
+    dec = rows[len(layers):]
+    print('decoder+lm GEMM launches', len(dec), 'time ms',
+          sum(r[2] for r in dec) / 1e6)
+    others = db.execute(
+        "select name, count(*), sum(end-start) from kernels where name not "
+        "like '%igemm%' group by name order by 3 desc limit 12").fetchall()
+    for nm, c, t in others:
+        print(f'  {nm[:60]:60s} x{c:5d} {t/1e6/passes:8.2f} ms/pass')
+
+
+if __name__ == '__main__':
+    main()
