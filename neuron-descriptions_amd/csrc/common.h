@@ -71,6 +71,7 @@ struct GemmArgs {
   int aux_split;      // 1: aux is in split format
   float acc_scale;    // accumulators are multiplied by this (1 / weight scale)
   int out_mode;       // filled by the launcher (OUT_*)
+  int tile_hint;      // 0 auto, 1 force 256x128x3-stage, 2 force 128x128x2-stage
 };
 
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2 };

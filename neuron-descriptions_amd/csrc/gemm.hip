@@ -40,6 +40,7 @@
 //   sees 16-byte per-lane accesses covering whole 256-B row segments.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -82,18 +83,22 @@ __device__ inline void join8(f32x4 hi, f32x4 lo, float* v) {
   for (int e = 0; e < 8; ++e) v[e] = (float)h[e] + (float)l[e];
 }
 
-template <int BM, int BN, int WM, int WN, bool CIN32, bool SPLIT>
-__global__ __launch_bounds__(256) void igemm_kernel(GemmArgs g, int tiles_m,
-                                                     int tiles_n) {
+template <int BM, int BN, int STAGES, bool CIN32, bool SPLIT>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_kernel(
+    GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int BK = 32;
+  constexpr int WM = 64, WN = 64;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
-  static_assert(WN == 64 && WM == 64, "epilogues assume 64x64 wave tiles");
-  constexpr int A_ITERS = BM / 32, B_ITERS = BN / 32;
+  constexpr int NW = (BM / WM) * WAVES_N;    // waves per workgroup (4 or 8)
+  constexpr int LROWS = NW * 8;              // tile rows covered per loader pass
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  static_assert(STAGES == 2 || STAGES == 3, "2- or 3-deep LDS ring");
+  constexpr int A_ITERS = BM / LROWS, B_ITERS = BN / LROWS;
+  constexpr int LOADS = A_ITERS + B_ITERS;   // DMA instructions per wave per stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                 // [2][BM*32]
-  float* Bs = smem + 2 * BM * BK;   // [2][BN*32]
+  float* As = smem;                      // [STAGES][BM*32]
+  float* Bs = smem + STAGES * BM * BK;   // [STAGES][BN*32]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -112,13 +117,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmArgs g, int tiles_m,
   const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 
   // ---- loader setup ---------------------------------------------------------
-  const int lrow = tid >> 3;                       // 0..31
+  const int lrow = tid >> 3;                       // 0..LROWS-1
   const int kc = (tid & 7) ^ ((tid >> 4) & 7);     // swizzled source chunk
   RowInfo ra[A_ITERS];
   const int HoWo = g.Ho * g.Wo;
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
-    int m = tile_m * BM + it * 32 + lrow;
+    int m = tile_m * BM + it * LROWS + lrow;
     m = m < g.M ? m : g.M - 1;
     const int img = m / HoWo;
     const int rem = m - img * HoWo;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmArgs g, int tiles_m,
   const float* rb[B_ITERS];
 #pragma unroll
   for (int it = 0; it < B_ITERS; ++it) {
-    int n = tile_n * BN + it * 32 + lrow;
+    int n = tile_n * BN + it * LROWS + lrow;
     n = n < g.N ? n : g.N - 1;
     rb[it] = g.W + (long)n * g.Kp + kc * 4;
   }
@@ -162,14 +167,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmArgs g, int tiles_m,
           inb ? ra[it].base + ((long)hi * g.Wd + wi) * g.a_pix_stride + cin
               : g.zero;
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
-                                       (LDS_AS void*)(adst + it * (32 * BK)),
+                                       (LDS_AS void*)(adst + it * (LROWS * BK)),
                                        16, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it) {
       __builtin_amdgcn_global_load_lds(
           (const GLOBAL_AS void*)(rb[it] + kt * BK),
-          (LDS_AS void*)(bdst + it * (32 * BK)), 16, 0, 0);
+          (LDS_AS void*)(bdst + it * (LROWS * BK)), 16, 0, 0);
     }
   };
 
@@ -201,13 +206,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmArgs g, int tiles_m,
     bswz[j] = (row >> 1) & 7;
   }
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+  auto compute = [&](int cur) {
     const float* Ab = As + cur * (BM * BK);
     const float* Bb = Bs + cur * (BN * BK);
     if constexpr (!SPLIT) {
@@ -266,8 +265,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmArgs g, int tiles_m,
           }
       }
     }
+  };
+
+  if constexpr (STAGES == 2) {
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // 3-deep ring, two k-tiles in flight: the DMA of tile kt+2 is issued
+    // before the MFMAs of tile kt, and only tile kt+1 is waited for (counted
+    // vmcnt + raw s_barrier, so the newest LOADS stay in flight ACROSS the
+    // barrier instead of being drained by a __syncthreads fence).
+    stage(0, 0);
+    if (nk > 1) {
+      stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      int nxt2 = cur + 2;
+      nxt2 = nxt2 >= 3 ? nxt2 - 3 : nxt2;
+      if (kt + 2 < nk) stage(nxt2, kt + 2);
+      compute(cur);
+      if (kt + 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == 3 ? 0 : cur + 1;
+    }
   }
   if constexpr (SPLIT) {
 #pragma unroll
@@ -486,11 +523,14 @@ int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool CIN32, bool SPLIT>
+template <int BM, int BN, int STAGES, bool CIN32, bool SPLIT>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  const size_t lds = size_t(2) * (BM + BN) * 32 * sizeof(float);
-  auto kern = igemm_kernel<BM, BN, WM, WN, CIN32, SPLIT>;
+  constexpr int NT = (BM / 64) * (BN / 64) * 64;
+  size_t lds = size_t(STAGES) * (BM + BN) * 32 * sizeof(float);
+  const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
+  if (lds < stage_bytes) lds = stage_bytes;
+  auto kern = igemm_kernel<BM, BN, STAGES, CIN32, SPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
     MILAN_CHECK_HIP(hipFuncSetAttribute(
@@ -498,7 +538,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, g,
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, g,
                      tiles_m, tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
@@ -540,8 +580,18 @@ static bool aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
 
+static int env_tile_hint() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MILAN_TILE_HINT");  // experiments only
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   const bool cin32 = (g.Cin % 32 == 0);
+  if (g.tile_hint == 0) g.tile_hint = env_tile_hint();
   // pick the epilogue form
   if (g.out_split || g.aux_split) {
     MILAN_REQUIRE(g.out_split && g.N % 8 == 0 && g.ldc % 8 == 0 && aligned16(g.C) &&
@@ -566,15 +616,21 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     MILAN_REQUIRE(cin32, MILAN_ERR_SHAPE,
                   "gemm: split-f16 operands need Cin %% 32 == 0 (Cin=%d)", g.Cin);
     if (g.acc_scale == 0.f) g.acc_scale = 1.f;
-    if (g.N <= 64) return launch_cfg<256, 64, 64, 64, true, true>(g, s);
-    return launch_cfg<128, 128, 64, 64, true, true>(g, s);
+    if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
+    if (g.tile_hint == 1 || (g.tile_hint == 0 && g.K >= 512 && g.M >= 2048))
+      return launch_cfg<256, 128, 3, true, true>(g, s);
+    return launch_cfg<128, 128, 2, true, true>(g, s);
   }
   if (g.N <= 64) {
-    return cin32 ? launch_cfg<256, 64, 64, 64, true, false>(g, s)
-                 : launch_cfg<256, 64, 64, 64, false, false>(g, s);
+    return cin32 ? launch_cfg<256, 64, 2, true, false>(g, s)
+                 : launch_cfg<256, 64, 2, false, false>(g, s);
   }
-  return cin32 ? launch_cfg<128, 128, 64, 64, true, false>(g, s)
-               : launch_cfg<128, 128, 64, 64, false, false>(g, s);
+  // (the 8-wave 3-stage tile measured 4% slower than 128x128x2 in F32 mode,
+  // where one k-tile is 4096 MFMA cycles and latency is already hidden)
+  if (cin32 && g.tile_hint == 1)
+    return launch_cfg<256, 128, 3, true, false>(g, s);
+  return cin32 ? launch_cfg<128, 128, 2, true, false>(g, s)
+               : launch_cfg<128, 128, 2, false, false>(g, s);
 }
 
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
