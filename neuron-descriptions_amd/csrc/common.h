@@ -152,6 +152,8 @@ struct milan_ctx {
   milan_dims d{};
   bool finalized = false;
   int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16
+  float* scratch = nullptr;   // per-call split-conversion scratch (workspace)
+  size_t scratch_floats = 0;
   std::map<std::string, milan::Tensor> raw;  // named reference tensors
   // weight arena (library-owned, freed in milan_destroy)
   std::vector<void*> owned;

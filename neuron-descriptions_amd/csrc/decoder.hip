@@ -71,6 +71,8 @@ static int pack_linear(milan_ctx* c, const std::string& wname,
   hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, s, w->dev, n,
                      k, out->kp, out->w);
   MILAN_CHECK_HIP(hipGetLastError());
+  if (k % 32 == 0)
+    MILAN_TRY(make_split_weight(c, out->w, n, out->kp, &out->ws, &out->ws_inv, s));
   if (!bname.empty()) {
     const Tensor* b = find(c, bname);
     MILAN_REQUIRE(b && b->numel() == n, MILAN_ERR_STATE, "missing/bad bias %s",
@@ -538,6 +540,26 @@ static inline int nblk(long total, int cap = 16384) {
   return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
 }
 
+// y = epi(A W^T + b): fp32 MFMA, or -- in split-f16 mode, when the layer has a
+// split weight copy -- A is first rewritten as (hi,lo) f16 pairs into the
+// context's scratch and the 3xf16 MFMA kernel runs (outputs stay fp32).
+static int lin(milan_ctx* c, const float* A, long lda, const LinearW& w, float* C,
+               int ldc, int M, int epi, hipStream_t s,
+               const float* aux = nullptr, int ldaux = 0) {
+  GemmArgs g = linear_args(A, lda, w.w, w.b, C, ldc, M, w.n, w.k, epi, c->zero,
+                           aux, ldaux);
+  if (c->precision == MILAN_PRECISION_SPLIT_F16 && w.ws && c->scratch &&
+      (size_t)M * w.k <= c->scratch_floats) {
+    MILAN_TRY(launch_f32_to_split(A, lda, c->scratch, w.k, M, w.k, 1.f, s));
+    g.A = c->scratch;
+    g.a_pix_stride = g.a_img_stride = w.k;
+    g.W = w.ws;
+    g.a_split = 1;
+    g.acc_scale = w.ws_inv;
+  }
+  return launch_gemm(g, s);
+}
+
 struct LmState {  // [layers][rows][Hl]
   float *h = nullptr, *c = nullptr;
   long rows = 0;
@@ -558,19 +580,14 @@ static int lm_step(milan_ctx* c, const int64_t* tok, int rows, LmState& st,
     const float* cl = st.c + (long)l * st.rows * Hl;
     float* hn = nx.h + (long)l * nx.rows * Hl;
     float* cn = nx.c + (long)l * nx.rows * Hl;
-    MILAN_TRY(launch_gemm(linear_args(in, in_dim, c->lm_ih[l].w, c->lm_ih[l].b,
-                                      gates, 4 * Hl, rows, 4 * Hl, in_dim,
-                                      EPI_BIAS, c->zero), s));
-    MILAN_TRY(launch_gemm(linear_args(hl, Hl, c->lm_hh[l].w, c->lm_hh[l].b,
-                                      gates, 4 * Hl, rows, 4 * Hl, Hl,
-                                      EPI_BIAS_ADD, c->zero, gates, 4 * Hl), s));
+    MILAN_TRY(lin(c, in, in_dim, c->lm_ih[l], gates, 4 * Hl, rows, EPI_BIAS, s));
+    MILAN_TRY(lin(c, hl, Hl, c->lm_hh[l], gates, 4 * Hl, rows, EPI_BIAS_ADD, s, gates, 4 * Hl));
     hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * Hl)),
                        dim3(256), 0, s, gates, cl, rows, Hl, hn, cn);
     in = hn;
     in_dim = Hl;
   }
-  MILAN_TRY(launch_gemm(linear_args(in, Hl, c->lm_out.w, c->lm_out.b, logits, V,
-                                    rows, V, Hl, EPI_BIAS, c->zero), s));
+  MILAN_TRY(lin(c, in, Hl, c->lm_out, logits, V, rows, EPI_BIAS, s));
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -584,6 +601,8 @@ struct DecBuf {
   int64_t *tok, *seqs;
   float *lm_alive, *lm_total;
   int32_t* len1;
+  float* scratch;
+  size_t scratch_floats;
 };
 
 static void dec_plan(const milan_ctx* c, int n, int k, int beam, int T, bool lm,
@@ -609,6 +628,11 @@ static void dec_plan(const milan_ctx* c, int n, int k, int beam, int T, bool lm,
   b->tok = a.get<int64_t>(R);
   b->seqs = a.get<int64_t>(R * (T + 1));
   b->len1 = a.get<int32_t>(2 * (size_t)n + 2);
+  {
+    const size_t rows = R > (size_t)n * k ? R : (size_t)n * k;
+    b->scratch_floats = rows * (size_t)(E + F);
+    b->scratch = a.get<float>(b->scratch_floats);
+  }
   b->lm_logits = nullptr;
   if (lm) {
     const int Hl = d.lm_hidden_size, El = d.lm_embedding_size;
@@ -646,9 +670,7 @@ static int check_dims(const milan_ctx* c, int k) {
 static int project_keys(milan_ctx* c, const float* features, int nk, float* keys,
                         hipStream_t s) {
   const milan_dims& d = c->d;
-  return launch_gemm(linear_args(features, d.feature_size, c->k2h.w, c->k2h.b,
-                                 keys, d.attention_size, nk, d.attention_size,
-                                 d.feature_size, EPI_BIAS, c->zero), s);
+  return lin(c, features, d.feature_size, c->k2h, keys, d.attention_size, nk, EPI_BIAS, s);
 }
 
 static int init_state_impl(milan_ctx* c, const float* features, int n, int k,
@@ -657,10 +679,8 @@ static int init_state_impl(milan_ctx* c, const float* features, int n, int k,
   const int F = d.feature_size, H = d.hidden_size;
   hipLaunchKernelGGL(mean_k_kernel, dim3(nblk((long)n * F)), dim3(256), 0, s,
                      features, n, k, F, pooled);
-  MILAN_TRY(launch_gemm(linear_args(pooled, F, c->init_h.w, c->init_h.b, h, H, n,
-                                    H, F, EPI_BIAS_TANH, c->zero), s));
-  MILAN_TRY(launch_gemm(linear_args(pooled, F, c->init_c.w, c->init_c.b, cc, H,
-                                    n, H, F, EPI_BIAS_TANH, c->zero), s));
+  MILAN_TRY(lin(c, pooled, F, c->init_h, h, H, n, EPI_BIAS_TANH, s));
+  MILAN_TRY(lin(c, pooled, F, c->init_c, cc, H, n, EPI_BIAS_TANH, s));
   return 0;
 }
 
@@ -669,6 +689,8 @@ int decoder_init_state(milan_ctx* c, const float* features, int n, int k,
   MILAN_TRY(check_dims(c, k));
   float* pooled = ws.get<float>((size_t)n * c->d.feature_size);
   MILAN_REQUIRE(pooled, MILAN_ERR_WORKSPACE, "init_state: workspace too small");
+  c->scratch_floats = (size_t)n * c->d.feature_size;
+  c->scratch = ws.get<float>(c->scratch_floats);  // may be null: fp32 path
   return init_state_impl(c, features, n, k, pooled, h, cc, s);
 }
 
@@ -682,8 +704,7 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
   const int F = d.feature_size, H = d.hidden_size, E = d.embedding_size,
             A = d.attention_size, V = d.vocab_size;
   const int ldx = E + F;
-  MILAN_TRY(launch_gemm(linear_args(h, H, c->q2h.w, c->q2h.b, b->q, A, rows, A, H,
-                                    EPI_BIAS, c->zero), s));
+  MILAN_TRY(lin(c, h, H, c->q2h, b->q, A, rows, EPI_BIAS, s));
   hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, b->q,
                      keys, c->att_w, c->att_b, rows, rpn, k, A, b->att);
   {
@@ -692,21 +713,14 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
                        features, rpn, k, F, b->ctx);
   }
   // gated = sigmoid(W_g h + b_g) * ctx  -> x[:, E:]
-  MILAN_TRY(launch_gemm(linear_args(h, H, c->gate.w, c->gate.b, b->x + E, ldx,
-                                    rows, F, H, EPI_BIAS_SIGMUL, c->zero, b->ctx,
-                                    F), s));
+  MILAN_TRY(lin(c, h, H, c->gate, b->x + E, ldx, rows, EPI_BIAS_SIGMUL, s, b->ctx, F));
   hipLaunchKernelGGL(embed_kernel, dim3(nblk((long)rows * E)), dim3(256), 0, s,
                      c->embedding, tok, rows, E, b->x, ldx);
-  MILAN_TRY(launch_gemm(linear_args(b->x, ldx, c->lstm_ih.w, c->lstm_ih.b,
-                                    b->gates, 4 * H, rows, 4 * H, ldx, EPI_BIAS,
-                                    c->zero), s));
-  MILAN_TRY(launch_gemm(linear_args(h, H, c->lstm_hh.w, c->lstm_hh.b, b->gates,
-                                    4 * H, rows, 4 * H, H, EPI_BIAS_ADD, c->zero,
-                                    b->gates, 4 * H), s));
+  MILAN_TRY(lin(c, b->x, ldx, c->lstm_ih, b->gates, 4 * H, rows, EPI_BIAS, s));
+  MILAN_TRY(lin(c, h, H, c->lstm_hh, b->gates, 4 * H, rows, EPI_BIAS_ADD, s, b->gates, 4 * H));
   hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * H)), dim3(256),
                      0, s, b->gates, cc, rows, H, hn, cn);
-  MILAN_TRY(launch_gemm(linear_args(hn, H, c->out.w, c->out.b, b->logits, V, rows,
-                                    V, H, EPI_BIAS, c->zero), s));
+  MILAN_TRY(lin(c, hn, H, c->out, b->logits, V, rows, EPI_BIAS, s));
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -748,6 +762,8 @@ int decoder_step(milan_ctx* c, const float* features, int rows, int k,
                 "state has h_lm or c_lm, but decoder has no lm");
   DecBuf b;
   dec_plan(c, rows, k, 1, 1, mi, ws, &b);
+  c->scratch = ws.off <= ws.size ? b.scratch : nullptr;
+  c->scratch_floats = b.scratch_floats;
   // per-row keys: the public step takes per-row features (un-hoisted API)
   MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
                 "step: workspace too small (%zu needed)", ws.off);
@@ -821,6 +837,8 @@ int decoder_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
   MILAN_REQUIRE(rows > 0 && L >= 1, MILAN_ERR_SHAPE, "lm_score: empty input");
   DecBuf b;
   dec_plan(c, rows, 1, 1, 1, true, ws, &b);
+  c->scratch = ws.off <= ws.size ? b.scratch : nullptr;
+  c->scratch_floats = b.scratch_floats;
   MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
                 "lm_score: workspace too small (%zu needed)", ws.off);
   return lm_score_impl(c, seqs, rows, L, seq_len, 1, out, &b, s);
@@ -854,6 +872,8 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   const bool need_lm = mi || strategy == MILAN_RERANK;
   DecBuf b;
   dec_plan(c, n, k, beam, length, need_lm, ws, &b);
+  c->scratch = ws.off <= ws.size ? b.scratch : nullptr;
+  c->scratch_floats = b.scratch_floats;
   MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
                 "decode: workspace too small (%zu needed, %zu given)", ws.off,
                 ws.size);

@@ -448,3 +448,29 @@ def test_split_f16_describe_end_to_end(dev):
     assert_tokens_match(out['tokens'], want['tokens'],
                         top2[..., 0] - top2[..., 1])
     ctx.close()
+
+
+def test_split_f16_decoder_matches_reference_goldens(dev, goldens, golden_meta):
+    """Decoder / LM GEMMs through the 3xf16 path: same goldens, same bounds."""
+    ctx, sd, feats, nv = _dec(golden_meta['dec_full'], dev)
+    ctx.set_precision('split_f16')
+    h, c = ctx.init_state(feats)
+    close(h, goldens['g2_full_h'], 1e-4, 1e-5)
+    pred, att, h2, _, _, _ = ctx.step(feats, goldens['g3_full_tokens'],
+                                      goldens['g2_full_h'],
+                                      goldens['g2_full_c'], None, None, 0.2)
+    close(pred, goldens['g3_full_pred'], 1e-4, 1e-4)
+    close(att, goldens['g3_full_att'], 1e-4, 1e-5)
+    close(h2, goldens['g3_full_h'], 1e-4, 1e-5)
+    out = ctx.decode(feats, hip.GREEDY, 15, 1, False, 0.2)
+    assert_tokens_match(out['tokens'], goldens['g4_full_tokens'],
+                        goldens['g4_full_top2gap'])
+    close(out['scores'], goldens['g4_full_scores'], 1e-4, 1e-3)
+    seqs = torch.cat(
+        [torch.full((3, 1), nv, dtype=torch.long), goldens['g4_full_tokens']],
+        1)
+    close(ctx.lm_score(seqs), goldens['g5_full_lm_scores'], 1e-4, 1e-3)
+    want_t, want_s = O.beam_search(feats, sd, nv, nv + 1, 15, 16)
+    outb = ctx.decode(feats, hip.RERANK, 15, 16, False, 0.2)
+    _check_beams(outb, want_t, want_s, want_t.shape[2])
+    ctx.close()
