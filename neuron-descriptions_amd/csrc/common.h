@@ -71,6 +71,7 @@ struct GemmArgs {
   int aux_split;      // 1: aux is in split format
   float acc_scale;    // accumulators are multiplied by this (1 / weight scale)
   int out_mode;       // filled by the launcher (OUT_*)
+  int debug;          // ablation switches for timing experiments (0 in production)
   int tile_hint;      // 0 auto, 1 force 256x128x3-stage, 2 force 128x128x2-stage
 };
 
