@@ -11,6 +11,8 @@
 // 226-235); bn1+relu+maxpool run as one fused kernel.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace milan {
 
 static constexpr float kBnEps = 1e-5f;  // torchvision 0.12 BatchNorm2d default
@@ -461,10 +463,24 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   return 0;
 }
 
+// Images per encoder pass: bounds the activation workspace (16 MB/image).
+// Smaller sub-batches were tried for Infinity-Cache locality and lost (tail
+// effects of the smaller GEMM grids dominate); MILAN_ENC_SUB overrides.
+static int encoder_sub_batch() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("MILAN_ENC_SUB");
+    v = e ? atoi(e) : 3840;  // measured: 240 -15%, 480 -8%, 960 -4% vs 3840
+    if (v < 1) v = 3840;
+  }
+  return v;
+}
+
 size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W) {
   Arena a; a.dry = true;
   EncPlan pl;
-  plan(c, n_images, H, W, a, &pl);
+  const int sub = encoder_sub_batch();
+  plan(c, n_images < sub ? n_images : sub, H, W, a, &pl);
   return a.off;
 }
 
@@ -491,9 +507,31 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
   return g;
 }
 
+static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
+                             const void* masks, int mask_dtype, int n, int H,
+                             int W, float* features, Arena& ws, hipStream_t s);
+
 int encoder_run(milan_ctx* c, const void* images, int image_dtype,
                 const void* masks, int mask_dtype, int n, int H, int W,
                 float* features, Arena& ws, hipStream_t s) {
+  const int sub = encoder_sub_batch();
+  const size_t isz = image_dtype == MILAN_DTYPE_U8 ? 1 : 4;
+  const size_t msz = mask_dtype == MILAN_DTYPE_U8 ? 1 : 4;
+  for (int lo = 0; lo < n; lo += sub) {
+    const int cnt = n - lo < sub ? n - lo : sub;
+    Arena a = ws;  // every pass reuses the same scratch
+    const char* im = (const char*)images + (size_t)lo * 3 * H * W * isz;
+    const char* mk = masks ? (const char*)masks + (size_t)lo * H * W * msz : nullptr;
+    MILAN_TRY(encoder_run_batch(c, im, image_dtype, mk, mask_dtype, cnt, H, W,
+                                features + (size_t)lo * c->d.feature_size, a, s));
+    if (a.off > ws.off) ws.off = a.off > ws.size ? ws.size : ws.off;
+  }
+  return 0;
+}
+
+static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
+                             const void* masks, int mask_dtype, int n, int H,
+                             int W, float* features, Arena& ws, hipStream_t s) {
   MILAN_REQUIRE(c->stem.w != nullptr, MILAN_ERR_STATE,
                 "encoder weights were not uploaded");
   MILAN_REQUIRE(n > 0 && H >= 32 && W >= 32, MILAN_ERR_SHAPE,

@@ -567,6 +567,7 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   // One DMA piece (1 KB per wave) of k-tile kt into ring slot buf: pieces
   // 0..A_ITERS-1 are A rows, the rest W rows.  Branch-free address generation
   // so the pieces can be interleaved with the MFMAs of the current tile.
+  const int nk_total = g.Kp / BK;
   // (kh, kw, cin0) of the k-tile that will be issued next, advanced
   // incrementally (no integer divisions in the main loop).
   int is_kh = 0, is_kw = 0, is_cin0 = 0;
@@ -577,29 +578,33 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
       if (++is_kw == g.KW) { is_kw = 0; ++is_kh; }
     }
   };
-  auto issue_piece = [&](int buf, int kt, int piece) {
+  // `live` (wave-uniform) is false for the dummy tiles issued past the end of
+  // K: they read the zero page into a ring slot nobody will consume again, so
+  // that every iteration issues exactly LOADS pieces (constant vmcnt counts,
+  // branch-free loop body the scheduler can interleave with the MFMAs).
+  auto issue_piece = [&](int buf, int kt, bool live, int piece) {
     if (piece < A_ITERS) {
       const int it = piece;
       const long toff = ((long)is_kh * g.Wd + is_kw) * g.a_pix_stride + is_cin0;
       const int hi = ra[it].hi0 + is_kh, wi = ra[it].wi0 + is_kw;
-      const bool inb = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.Wd;
+      const bool inb = live && (unsigned)hi < (unsigned)g.H &&
+                       (unsigned)wi < (unsigned)g.Wd;
       const float* src = inb ? ra[it].base + toff : g.zero;
-      if (g.debug & 4) src = rb[0] + kt * BK;  // timing experiment: L2-hot source
       float* adst = As + buf * (BM * BK) + wave * (16 * BK) + it * (LROWS * BK);
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
                                        (LDS_AS void*)adst, 16, 0, 0);
     } else {
       const int it = piece - A_ITERS;
+      const float* src = live ? rb[it] + kt * BK : g.zero;
       float* bdst = Bs + buf * (BN * BK) + wave * (16 * BK) + it * (LROWS * BK);
-      __builtin_amdgcn_global_load_lds(
-          (const GLOBAL_AS void*)(rb[it] + kt * BK), (LDS_AS void*)bdst, 16, 0,
-          0);
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
+                                       (LDS_AS void*)bdst, 16, 0, 0);
     }
     if (piece == LOADS - 1) advance_tap();
   };
   auto stage = [&](int buf, int kt) {
 #pragma unroll
-    for (int p = 0; p < LOADS; ++p) issue_piece(buf, kt, p);
+    for (int p = 0; p < LOADS; ++p) issue_piece(buf, kt, kt < nk_total, p);
   };
 
   f32x16 acc[TM][TN];
@@ -629,9 +634,14 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   // MFMAs of tile `cur`, with the DMA pieces of tile `ktn` (ring slot `nxt`,
   // when do_stage) issued between the MFMA groups so that their issue cost
   // and address arithmetic hide under the matrix pipe.
-  auto compute = [&](int cur, bool do_stage, int nxt, int ktn) {
+  // MFMAs of tile `cur`; the DMA pieces of tile `ktn` (ring slot `nxt`) are
+  // issued between the MFMA groups and the A fragments of row-tile i+1 are
+  // fetched while row-tile i multiplies, so address arithmetic, DMA issue and
+  // LDS latency hide under the matrix pipe.
+  auto compute = [&](int cur, int nxt, int ktn) {
     const float* Ab = As + cur * (BM * BK);
     const float* Bb = Bs + cur * (BN * BK);
+    const bool live = ktn < nk_total;
     // lanes 0-31: group 0 (channels 0-7), lanes 32-63: group 1 (channels 8-15)
     const int chi = 2 * fhalf, clo = chi + 1;
     f32x4 ah[TM], al[TM], bh[TN], bl[TN];
@@ -640,19 +650,20 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
       bh[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] + ((chi ^ bswz[j]) << 2));
       bl[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] + ((clo ^ bswz[j]) << 2));
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      ah[i] = *reinterpret_cast<const f32x4*>(Ab + aoff[i] + ((chi ^ aswz[i]) << 2));
-      al[i] = *reinterpret_cast<const f32x4*>(Ab + aoff[i] + ((clo ^ aswz[i]) << 2));
-    }
+    ah[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((chi ^ aswz[0]) << 2));
+    al[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((clo ^ aswz[0]) << 2));
     constexpr int PER = (LOADS + TM - 1) / TM;  // pieces per MFMA group
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (do_stage) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q)
-          if (i * PER + q < LOADS) issue_piece(nxt, ktn, i * PER + q);
+      if (i + 1 < TM) {
+        ah[i + 1] = *reinterpret_cast<const f32x4*>(Ab + aoff[i + 1] +
+                                                    ((chi ^ aswz[i + 1]) << 2));
+        al[i + 1] = *reinterpret_cast<const f32x4*>(Ab + aoff[i + 1] +
+                                                    ((clo ^ aswz[i + 1]) << 2));
       }
+#pragma unroll
+      for (int q = 0; q < PER; ++q)
+        if (i * PER + q < LOADS) issue_piece(nxt, ktn, live, i * PER + q);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -665,38 +676,25 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
     }
   };
 
-  // prologue: up to STAGES-1 tiles in flight, wait for the first
+  // prologue: STAGES-1 tiles in flight (dummy ones if K is short), wait for
+  // the first
   constexpr int AHEAD = STAGES - 1;
 #pragma unroll
-  for (int t = 0; t < AHEAD; ++t)
-    if (t < nk) stage(t, t);
-  auto wait_for_next = [&](int issued_after) {
-    // `issued_after` = number of younger tiles whose DMA may stay in flight
-    if (issued_after >= 2 && AHEAD >= 3) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-    } else if (issued_after >= 1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  };
-  {
-    const int younger = (nk < AHEAD ? nk : AHEAD) - 1;
-    wait_for_next(younger);
-  }
+  for (int t = 0; t < AHEAD; ++t) stage(t, t);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
   __builtin_amdgcn_s_barrier();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     int nxt = cur + AHEAD;
     nxt = nxt >= STAGES ? nxt - STAGES : nxt;
-    compute(cur, kt + AHEAD < nk && !(g.debug & 2), nxt, kt + AHEAD);
-    // tiles kt+2 .. kt+AHEAD (those that exist) may remain in flight
-    int younger = nk - 1 - (kt + 1);
-    younger = younger > AHEAD - 1 ? AHEAD - 1 : younger;
-    wait_for_next(younger < 0 ? 0 : younger);
+    compute(cur, nxt, kt + AHEAD);
+    // tile kt+1 must have landed; the AHEAD-1 younger tiles stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
     __builtin_amdgcn_s_barrier();
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tiles
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -877,6 +875,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     if (g.tile_hint == 3) return launch_split16<256, 256, 4>(g, s);
     if (g.tile_hint == 1) return launch_cfg<256, 128, 3, true, true>(g, s);
     if (g.tile_hint == 2) return launch_cfg<128, 128, 2, true, true>(g, s);
+    if (g.M >= 256 && g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);
     if (g.M >= 256) return launch_split16<256, 128, 3>(g, s);
     return launch_cfg<128, 128, 2, true, true>(g, s);
   }
