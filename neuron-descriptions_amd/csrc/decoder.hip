@@ -286,6 +286,88 @@ __device__ inline void block_topk(float* vals, int n, int k, float* out_v,
   }
 }
 
+// ---- exact top-k by threshold search + sort ----------------------------------
+// The k-th largest value is found by bisection on an order-preserving integer
+// key (<= 32 block-wide counts), the winners are gathered and a bitonic sort
+// orders them by (value desc, index asc) -- the tie rule of the oracle.  About
+// 10x faster than k rounds of block argmax for k = 50, V = 5004.
+__device__ inline unsigned fkey(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// vals: LDS [n] (preserved); 2 <= k <= 256, k <= n; scratch: 528 LDS words.
+__device__ inline void block_topk_fast(const float* vals, int n, int k,
+                                       float* out_v, int* out_i,
+                                       unsigned* scratch) {
+  unsigned* cnt = scratch;                          // [8]
+  float* cv = reinterpret_cast<float*>(scratch + 8);      // [256]
+  int* ci = reinterpret_cast<int*>(scratch + 8 + 256);    // [256]
+  const int tid = threadIdx.x;
+  unsigned lo = 0u, hi = 0xFFFFFFFFu;  // invariant: count(key >= lo) >= k
+  for (int it = 0; it < 32 && lo < hi; ++it) {
+    const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);
+    int c = 0;
+    for (int i = tid; i < n; i += 256) c += fkey(vals[i]) >= mid;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __syncthreads();
+    if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)c;
+    __syncthreads();
+    const int total = (int)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+    if (total >= k) lo = mid; else hi = mid - 1u;
+  }
+  const unsigned T = lo;
+  __syncthreads();
+  if (tid == 0) { cnt[4] = 0u; cnt[5] = 0u; }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const float v = vals[i];
+    const unsigned key = fkey(v);
+    if (key > T) {
+      const unsigned p = atomicAdd(&cnt[4], 1u);
+      cv[p] = v; ci[p] = i;
+    } else if (key == T) {
+      atomicAdd(&cnt[5], 1u);
+    }
+  }
+  __syncthreads();
+  const int ngt = (int)cnt[4], neq = (int)cnt[5], need = k - ngt;
+  __syncthreads();
+  if (neq == need) {
+    for (int i = tid; i < n; i += 256) {
+      const float v = vals[i];
+      if (fkey(v) == T) {
+        const unsigned p = atomicAdd(&cnt[4], 1u);
+        cv[p] = v; ci[p] = i;
+      }
+    }
+  } else if (tid == 0) {  // ties across the boundary: lowest indices win (rare)
+    int got = 0;
+    for (int i = 0; i < n && got < need; ++i)
+      if (fkey(vals[i]) == T) { cv[ngt + got] = vals[i]; ci[ngt + got] = i; ++got; }
+  }
+  __syncthreads();
+  int P = 64;
+  while (P < k) P <<= 1;
+  if (tid >= k && tid < P) { cv[tid] = -INFINITY; ci[tid] = 0x7fffffff; }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = tid ^ stride;
+      if (tid < P && partner > tid) {
+        const float av = cv[tid], bv = cv[partner];
+        const int ai = ci[tid], bi = ci[partner];
+        const bool a_first = av > bv || (av == bv && ai < bi);
+        const bool up = (tid & size) == 0;
+        if (up ? !a_first : a_first) {
+          cv[tid] = bv; ci[tid] = bi; cv[partner] = av; ci[partner] = ai;
+        }
+      }
+      __syncthreads();
+    }
+  if (tid < k) { out_v[tid] = cv[tid]; out_i[tid] = ci[tid]; }
+}
+
 // Per row: pred = log_softmax(logits) [- lambda * log_softmax(lm_logits)]
 // (decoders.py:621,624-630); optionally store pred; then the top-k of pred
 // (k = beam for allennlp's per-node topk, k = 1 for greedy argmax).  Rows whose
@@ -336,7 +418,11 @@ __global__ __launch_bounds__(256) void row_select_kernel(
     }
     return;
   }
-  block_topk(pred, V, k, cand_v + (long)r * k, cand_i + (long)r * k, red, redi);
+  if (k >= 2 && k <= 256)
+    block_topk_fast(pred, V, k, cand_v + (long)r * k, cand_i + (long)r * k,
+                    reinterpret_cast<unsigned*>(sm + V + 8));
+  else
+    block_topk(pred, V, k, cand_v + (long)r * k, cand_i + (long)r * k, red, redi);
 }
 
 // allennlp beam restriction: per neuron, top-`beam` of the beam_prev*beam
@@ -359,7 +445,11 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(
     vals[i] = cand_v[(long)n * nc + i] + lp;
   }
   __syncthreads();
-  block_topk(vals, nc, beam, outv, outi, red, redi);
+  if (beam >= 2 && beam <= 256)
+    block_topk_fast(vals, nc, beam, outv, outi,
+                    reinterpret_cast<unsigned*>(redi + 4));
+  else
+    block_topk(vals, nc, beam, outv, outi, red, redi);
   __syncthreads();
   for (int j = tid; j < beam; j += 256) {
     const int idx = outi[j];
@@ -725,7 +815,7 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
   return 0;
 }
 
-static size_t row_select_lds(int V) { return sizeof(float) * (V + 8); }
+static size_t row_select_lds(int V) { return sizeof(float) * (V + 8 + 528); }
 
 static int launch_row_select(const float* logits, const float* lm_logits,
                              float lambda, int rows, int V, int k,
@@ -917,7 +1007,7 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   }
 
   // ---- beam search (allennlp 2.10 semantics, fixed `length` steps) ----------
-  const size_t merge_lds = sizeof(float) * ((size_t)beam * beam + 2 * beam + 16);
+  const size_t merge_lds = sizeof(float) * ((size_t)beam * beam + 2 * beam + 16 + 528);
   MILAN_REQUIRE(merge_lds <= 64 * 1024, MILAN_ERR_ARG,
                 "beam_size %d too large for the merge kernel", beam);
   int beam_prev = 1, rows = n, lpcur = 0;
