@@ -36,6 +36,7 @@ GFLOP_ENCODER = 233.97
 GFLOP_DECODER = {1: 0.494, 16: 6.456, 50: 19.970}
 GFLOP_LM = {16: 3.057, 50: 9.552}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, f32-in MFMA
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA (not the 2:1-sparse figure)
 
 
 def algorithmic_gflop(beam: int, rerank: bool, k: int = 15, f: int = 3904,
@@ -100,6 +101,14 @@ def main():
                     help='neurons for the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-profile', action='store_true',
                     help='do not bracket GEMM launches with HIP events')
+    ap.add_argument('--precision', default='split_f16',
+                    choices=['split_f16', 'f32'],
+                    help='split_f16: operands as (hi,lo) f16 pairs, 3 f16 '
+                    'MFMAs per product, fp32 accumulate (fp32-GEMM-class error, '
+                    'same parity suite); f32: exact fp32-in MFMA')
+    ap.add_argument('--also-f32-steps', type=int, default=2,
+                    help='extra timed steps in f32 mode, reported under '
+                    '"f32_mode" (0 = skip)')
     args = ap.parse_args()
 
     rank, world, local = sharding.init_from_env(args.gpus)
@@ -114,6 +123,7 @@ def main():
         if rank == 0 else None
     sd_dev = sharding.broadcast_state_dict(sd, device, src=0)
     ctx = hip.Context(hip.make_dims(sd_dev, nv, blocks=blocks), sd_dev, device)
+    ctx.set_precision(args.precision)
     del sd_dev
 
     strategy = {'greedy': hip.GREEDY, 'beam': hip.BEAM,
@@ -149,6 +159,25 @@ def main():
         hip.profile_enable(False)
     elapsed = sharding.max_over_ranks(elapsed, device)
 
+    # secondary measurement in the exact-fp32 mode (same workload, fewer steps)
+    f32_mode = None
+    if args.precision != 'f32' and args.also_f32_steps > 0:
+        ctx.set_precision('f32')
+        step(0)
+        sharding.barrier()
+        torch.cuda.synchronize()
+        hip.profile_enable(True)
+        t1 = time.perf_counter()
+        for i in range(args.also_f32_steps):
+            step(i)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        e32 = sharding.max_over_ranks(time.perf_counter() - t1, device)
+        ms32, _, n32 = hip.profile_read()
+        hip.profile_enable(False)
+        ctx.set_precision(args.precision)
+        f32_mode = (e32, ms32, n32)
+
     # final gather of the top-1 token ids + scores (section 8e); not timed
     tokens = torch.cat([o['tokens'] for o in outs])
     scores = torch.cat([o['scores'] for o in outs])
@@ -171,7 +200,9 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': ('f32' if args.precision == 'f32' else
+                  'f32-equivalent: operands split into (hi,lo) f16 pairs (22 '
+                  'significant bits), 3 f16 MFMAs per product, f32 accumulate'),
         'data': 'synthetic',
         'config': {
             'workload': (f'{args.steps * args.chunk} neurons/GPU x k=15 x '
@@ -190,13 +221,20 @@ def main():
         per_launch_flop = g_alg * 1e9 * args.steps * args.chunk / gemm_launches
         avg_ms = gemm_ms / gemm_launches
         achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
+        split = args.precision != 'f32'
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         result['roofline'] = {
             'bound': 'mfma',
-            'kernel': 'igemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
+            'kernel': ('igemm_split16_kernel / igemm_kernel<SPLIT> '
+                       '(v_mfma_f32_32x32x16_f16, 3 per product)' if split else
+                       'igemm_kernel (v_mfma_f32_32x32x2_f32)'),
             'achieved': achieved,
-            'peak': PEAK_F32_MFMA_TFLOPS,
+            'peak': peak,
             'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+            'frac': achieved / peak,
+            # the matrix cores execute 3 f16 MFMA flops per algorithmic flop
+            'mfma_issue_frac': (3 * achieved / peak) if split else
+            achieved / peak,
             'traffic': None,
             'launches': gemm_launches,
             'avg_launch_ms': avg_ms,
@@ -207,6 +245,19 @@ def main():
         }
     else:
         result['roofline'] = None
+    if f32_mode is not None:
+        e32, ms32, n32 = f32_mode
+        g_alg = algorithmic_gflop(beam, strategy == hip.RERANK)
+        n32_neurons = args.also_f32_steps * args.chunk
+        result['f32_mode'] = {
+            'value': n32_neurons * world / e32,
+            'unit': 'neuron-descriptions/sec',
+            'steps': args.also_f32_steps,
+            'roofline_achieved_tflops': g_alg * 1e9 * n32_neurons / (ms32 * 1e-3) / 1e12,
+            'roofline_frac_of_f32_mfma_peak':
+                g_alg * 1e9 * n32_neurons / (ms32 * 1e-3) / 1e12 /
+                PEAK_F32_MFMA_TFLOPS,
+        }
     if world == 1 and args.cpu_sample > 0:
         sd = synthetic.milan_state_dict(nv + 4, 'resnet101', seed=0)
         result['cpu_baseline'] = cpu_baseline(sd, nv, beam, args.length,
