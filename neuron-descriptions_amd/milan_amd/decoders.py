@@ -132,6 +132,11 @@ class Decoder(nn.Module):
         self.temperature = temperature
         self.beam_size = beam_size
         self.chunk_size = 256  # neurons per HIP launch in predict()
+        # 'f32' (exact fp32 MFMA, the reference's arithmetic) or 'split_f16'
+        # (3 x f16 MFMA on (hi,lo) operand pairs: fp32-class error, ~2.2x
+        # faster); see DESIGN.md section 4.2.  MILAN_PRECISION sets the default.
+        import os
+        self.precision = os.environ.get('MILAN_PRECISION', 'f32')
 
         f = torch.float32
         fs, hs, es, v = (self.feature_size, hidden_size, embedding_size,
@@ -196,6 +201,8 @@ class Decoder(nn.Module):
                 self._ctx.close()
             self._ctx = hip.Context(dims, sd, device)
             self._ctx_key = key
+        if self._ctx.precision != self.precision:
+            self._ctx.set_precision(self.precision)
         return self._ctx
 
     # -- forward -------------------------------------------------------------------

@@ -165,3 +165,26 @@ def test_save_load_roundtrip_gives_same_descriptions(model, tmp_path):
     dec.save(tmp_path / 'm.pth')
     again = decoders.Decoder.load(tmp_path / 'm.pth').to('cuda')
     assert again(images, masks).captions == before
+
+
+def test_precision_switch_gives_same_captions(model):
+    """decoder.precision = 'split_f16' is an opt-in speed mode with fp32-class
+    error: same captions, features within the encoder tolerance."""
+    dec, sd = model
+    images, masks = synthetic.exemplars(4, k=K, size=SIZE, seed=25)
+    assert dec.precision == 'f32'
+    f32 = dec(images, masks)
+    feats32 = dec.encode(images, masks)
+    dec.precision = 'split_f16'
+    try:
+        sp = dec(images, masks)
+        feats_sp = dec.encode(images, masks)
+        assert dec._context().precision == 'split_f16'
+    finally:
+        dec.precision = 'f32'
+    assert sp.captions == f32.captions
+    torch.testing.assert_close(feats_sp, feats32, rtol=2e-3, atol=2e-4)
+    with pytest.raises(ValueError, match='unknown precision'):
+        dec.precision = 'bf16'
+        dec(images, masks)
+    dec.precision = 'f32'
