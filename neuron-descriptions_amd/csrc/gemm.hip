@@ -506,7 +506,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_kernel(
 // stores k-chunk p ^ ((r>>2)&3) (conflict-free for the DMA write and for the
 // row-per-lane ds_read_b128).
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int SHAPE>
 __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_kernel(
     GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int BK = 16;
@@ -571,40 +571,42 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   // (kh, kw, cin0) of the k-tile that will be issued next, advanced
   // incrementally (no integer divisions in the main loop).
   int is_kh = 0, is_kw = 0, is_cin0 = 0;
+  int is_kt = 0;  // k-tile described by (is_kh, is_kw, is_cin0)
   auto advance_tap = [&]() {
+    if (is_kt + 1 >= nk_total) return;  // dummy tiles re-read the last tile
+    ++is_kt;
     is_cin0 += BK;
     if (is_cin0 >= g.Cin) {
       is_cin0 = 0;
       if (++is_kw == g.KW) { is_kw = 0; ++is_kh; }
     }
   };
-  // `live` (wave-uniform) is false for the dummy tiles issued past the end of
-  // K: they read the zero page into a ring slot nobody will consume again, so
-  // that every iteration issues exactly LOADS pieces (constant vmcnt counts,
-  // branch-free loop body the scheduler can interleave with the MFMAs).
-  auto issue_piece = [&](int buf, int kt, bool live, int piece) {
+  // Past the end of K the loader keeps re-reading the last k-tile into ring
+  // slots nobody will consume again, so that every iteration issues exactly
+  // LOADS pieces (constant vmcnt counts, branch-free loop body that the
+  // scheduler can interleave with the MFMAs).
+  auto issue_piece = [&](int buf, int piece) {
     if (piece < A_ITERS) {
       const int it = piece;
       const long toff = ((long)is_kh * g.Wd + is_kw) * g.a_pix_stride + is_cin0;
       const int hi = ra[it].hi0 + is_kh, wi = ra[it].wi0 + is_kw;
-      const bool inb = live && (unsigned)hi < (unsigned)g.H &&
-                       (unsigned)wi < (unsigned)g.Wd;
+      const bool inb = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.Wd;
       const float* src = inb ? ra[it].base + toff : g.zero;
       float* adst = As + buf * (BM * BK) + wave * (16 * BK) + it * (LROWS * BK);
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
                                        (LDS_AS void*)adst, 16, 0, 0);
     } else {
       const int it = piece - A_ITERS;
-      const float* src = live ? rb[it] + kt * BK : g.zero;
+      const float* src = rb[it] + is_kt * BK;
       float* bdst = Bs + buf * (BN * BK) + wave * (16 * BK) + it * (LROWS * BK);
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
                                        (LDS_AS void*)bdst, 16, 0, 0);
     }
     if (piece == LOADS - 1) advance_tap();
   };
-  auto stage = [&](int buf, int kt) {
+  auto stage = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < LOADS; ++p) issue_piece(buf, kt, kt < nk_total, p);
+    for (int p = 0; p < LOADS; ++p) issue_piece(buf, p);
   };
 
   f32x16 acc[TM][TN];
@@ -638,10 +640,9 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   // issued between the MFMA groups and the A fragments of row-tile i+1 are
   // fetched while row-tile i multiplies, so address arithmetic, DMA issue and
   // LDS latency hide under the matrix pipe.
-  auto compute = [&](int cur, int nxt, int ktn) {
+  auto compute = [&](int cur, int nxt) {
     const float* Ab = As + cur * (BM * BK);
     const float* Bb = Bs + cur * (BN * BK);
-    const bool live = ktn < nk_total;
     // lanes 0-31: group 0 (channels 0-7), lanes 32-63: group 1 (channels 8-15)
     const int chi = 2 * fhalf, clo = chi + 1;
     f32x4 ah[TM], al[TM], bh[TN], bl[TN];
@@ -663,7 +664,7 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
       }
 #pragma unroll
       for (int q = 0; q < PER; ++q)
-        if (i * PER + q < LOADS) issue_piece(nxt, ktn, live, i * PER + q);
+        if (i * PER + q < LOADS) issue_piece(nxt, i * PER + q);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -674,20 +675,33 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
             as_f16x8(ah[i]), as_f16x8(bh[j]), acc[i][j], 0, 0, 0);
       }
     }
+    if constexpr (SHAPE == 1) {
+      // issue-slot shaping: fragments of the first row-tile, then one MFMA
+      // followed by a few of the remaining non-MFMA instructions, repeated
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // DS_READ
+#pragma unroll
+      for (int m = 0; m < TM * TN * 3; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+        if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); // VALU
+        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0); // SALU
+        if ((m & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // VMEM
+      }
+    }
   };
 
   // prologue: STAGES-1 tiles in flight (dummy ones if K is short), wait for
   // the first
   constexpr int AHEAD = STAGES - 1;
 #pragma unroll
-  for (int t = 0; t < AHEAD; ++t) stage(t, t);
+  for (int t = 0; t < AHEAD; ++t) stage(t);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
   __builtin_amdgcn_s_barrier();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     int nxt = cur + AHEAD;
     nxt = nxt >= STAGES ? nxt - STAGES : nxt;
-    compute(cur, nxt, kt + AHEAD);
+    compute(cur, nxt);
     // tile kt+1 must have landed; the AHEAD-1 younger tiles stay in flight
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -800,14 +814,14 @@ int gemm_profile_read(double* ms, double* flops, long long* launches) {
   return 0;
 }
 
-template <int BM, int BN, int STAGES>
-static int launch_split16(const GemmArgs& g, hipStream_t s) {
+template <int BM, int BN, int STAGES, int SHAPE>
+static int launch_split16_impl(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   constexpr int NT = (BM / 128) * (BN / 64) * 64;
   size_t lds = size_t(STAGES) * (BM + BN) * 16 * sizeof(float);
   const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
-  auto kern = igemm_split16_kernel<BM, BN, STAGES>;
+  auto kern = igemm_split16_kernel<BM, BN, STAGES, SHAPE>;
   static bool attr_set = false;
   if (!attr_set) {
     MILAN_CHECK_HIP(hipFuncSetAttribute(
@@ -819,6 +833,14 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
                      tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <int BM, int BN, int STAGES>
+static int launch_split16(const GemmArgs& g, hipStream_t s) {
+  static int shape = -1;
+  if (shape < 0) { const char* e = getenv("MILAN_SCHED"); shape = e ? atoi(e) : 0; }
+  if (shape == 1) return launch_split16_impl<BM, BN, STAGES, 1>(g, s);
+  return launch_split16_impl<BM, BN, STAGES, 0>(g, s);
 }
 
 static bool aligned16(const void* p) {
