@@ -101,6 +101,10 @@ def main():
                     help='neurons for the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-profile', action='store_true',
                     help='do not bracket GEMM launches with HIP events')
+    ap.add_argument('--from-host-steps', type=int, default=0,
+                    help='also time this many steps fed from pinned host uint8 '
+                    'tensors through the double-buffered ingest (PCIe-inclusive '
+                    'rate, reported under "pcie_inclusive"; never `value`)')
     ap.add_argument('--precision', default='split_f16',
                     choices=['split_f16', 'f32'],
                     help='split_f16: operands as (hi,lo) f16 pairs, 3 f16 '
@@ -178,6 +182,22 @@ def main():
         ctx.set_precision(args.precision)
         f32_mode = (e32, ms32, n32)
 
+    pcie = None
+    if args.from_host_steps > 0:
+        from milan_amd import ingest
+        nh = min(args.from_host_steps, n_steps_data)
+        host = [(images[i * args.chunk:(i + 1) * args.chunk].cpu().pin_memory(),
+                 masks[i * args.chunk:(i + 1) * args.chunk].cpu().pin_memory())
+                for i in range(nh)]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for im, mk in ingest.ChunkPrefetcher(lambda i: host[i % nh],
+                                             args.from_host_steps, device):
+            ctx.describe(im, mk, strategy, args.length, beam, False,
+                         args.temperature, group_size=16)
+        torch.cuda.synchronize()
+        pcie = args.from_host_steps * args.chunk / (time.perf_counter() - t2)
+
     # final gather of the top-1 token ids + scores (section 8e); not timed
     tokens = torch.cat([o['tokens'] for o in outs])
     scores = torch.cat([o['scores'] for o in outs])
@@ -245,6 +265,12 @@ def main():
         }
     else:
         result['roofline'] = None
+    if pcie is not None:
+        result['pcie_inclusive'] = {
+            'value': pcie * world, 'unit': 'neuron-descriptions/sec',
+            'steps': args.from_host_steps,
+            'note': 'pinned host uint8 -> pinned staging -> async H2D on a '
+                    'side stream, double buffered (milan_amd/ingest.py)'}
     if f32_mode is not None:
         e32, ms32, n32 = f32_mode
         g_alg = algorithmic_gflop(beam, strategy == hip.RERANK)

@@ -379,21 +379,42 @@ class Decoder(nn.Module):
                 spans = tqdm(spans, desc=display_progress_as)
             except ImportError:
                 pass
+        if fast is not None and hip.torch.cuda.is_available():
+            # memory-mapped uint8 dataset: worker thread -> pinned staging ->
+            # async H2D on a side stream, overlapped with the previous chunk
+            from milan_amd import ingest
+            dev = hip.require_device(self.device)
+            los = list(range(0, n, chunk))
+
+            def fetch(i):
+                images, masks = fast(los[i], min(n, los[i] + chunk))
+                return images, (masks if mask else None)
+
+            chunks = ingest.ChunkPrefetcher(fetch, len(los), dev)
+            if display_progress_as is not None:
+                try:
+                    from tqdm.auto import tqdm
+                    chunks = tqdm(chunks, total=len(los),
+                                  desc=display_progress_as)
+                except ImportError:
+                    pass
+            for images, masks in chunks:
+                with torch.no_grad():
+                    output = self(images, masks, group_size=batch_size,
+                                  **kwargs)
+                captions += list(output.captions)
+            return tuple(captions)
         for lo in spans:
             hi = min(n, lo + chunk)
-            if fast is not None:  # memory-mapped uint8 dataset: no collate
-                images, masks = fast(lo, hi)
-                inputs = (images, masks if mask else None)
+            loader = data.DataLoader(data.Subset(source, range(lo, hi)),
+                                     batch_size=hi - lo,
+                                     num_workers=num_workers)
+            batch = next(iter(loader))
+            if features is None:
+                inputs = (batch[image_index],
+                          batch[mask_index] if mask else None)
             else:
-                loader = data.DataLoader(data.Subset(source, range(lo, hi)),
-                                         batch_size=hi - lo,
-                                         num_workers=num_workers)
-                batch = next(iter(loader))
-                if features is None:
-                    inputs = (batch[image_index],
-                              batch[mask_index] if mask else None)
-                else:
-                    inputs = tuple(batch)
+                inputs = tuple(batch)
             with torch.no_grad():
                 output = self(*inputs, group_size=batch_size, **kwargs)
             captions += list(output.captions)
