@@ -425,6 +425,198 @@ __global__ __launch_bounds__(256) void row_select_kernel(
     block_topk(pred, V, k, cand_v + (long)r * k, cand_i + (long)r * k, red, redi);
 }
 
+// Register-resident variant of row_select_kernel for V <= 24*256: the row, its
+// log-softmax and the order-preserving keys never leave the VGPRs (24 values
+// per thread); LDS holds only reduction scratch and the <= 256 winners.  Same
+// results as row_select_kernel (same float operations, same tie rule).
+constexpr int kRowRegs = 24;
+
+__device__ inline float funkey(unsigned key) {
+  return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+}
+
+__global__ __launch_bounds__(256) void row_select_reg_kernel(
+    const float* __restrict__ logits, const float* __restrict__ lm_logits,
+    float lambda, int V, int k, const int64_t* __restrict__ last_tok, int stop,
+    float* __restrict__ cand_v, int* __restrict__ cand_i,
+    float* __restrict__ pred_out, long pred_stride) {
+  __shared__ float red[8];
+  __shared__ unsigned scratch[528];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long)r * V;
+  float p[kRowRegs];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < kRowRegs; ++j) {
+    const int i = tid + 256 * j;
+    p[j] = i < V ? x[i] : -INFINITY;
+    mx = fmaxf(mx, p[j]);
+  }
+  mx = block_max(mx, red);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < kRowRegs; ++j)
+    if (tid + 256 * j < V) s += expf(p[j] - mx);
+  s = block_sum(s, red);
+  const float ls = logf(s);
+  if (lm_logits) {
+    const float* y = lm_logits + (long)r * V;
+    float q[kRowRegs];
+    float my = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) {
+      const int i = tid + 256 * j;
+      q[j] = i < V ? y[i] : -INFINITY;
+      my = fmaxf(my, q[j]);
+    }
+    my = block_max(my, red);
+    float sy = 0.f;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j)
+      if (tid + 256 * j < V) sy += expf(q[j] - my);
+    sy = block_sum(sy, red);
+    const float lsy = logf(sy);
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j)
+      p[j] = ((p[j] - mx) - ls) - lambda * ((q[j] - my) - lsy);
+  } else {
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) p[j] = (p[j] - mx) - ls;
+  }
+  if (pred_out) {
+    float* po = pred_out + (long)r * pred_stride;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j)
+      if (tid + 256 * j < V) po[tid + 256 * j] = p[j];
+  }
+  if (k <= 0) return;
+  float* out_v = cand_v + (long)r * k;
+  int* out_i = cand_i + (long)r * k;
+  if (last_tok && last_tok[r] == stop) {
+    for (int j = tid; j < k; j += 256) {
+      out_v[j] = j == 0 ? 0.f : kFloatMin;
+      out_i[j] = j == 0 ? stop : (j - 1 < stop ? j - 1 : j);
+    }
+    return;
+  }
+  unsigned key[kRowRegs];
+  unsigned kmax = 0u, kmin = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < kRowRegs; ++j) {
+    const bool ok = tid + 256 * j < V;
+    key[j] = ok ? fkey(p[j]) : 0u;
+    if (ok) { kmax = max(kmax, key[j]); kmin = min(kmin, key[j]); }
+  }
+  unsigned* cnt = scratch;
+  float* cv = reinterpret_cast<float*>(scratch + 8);
+  int* ci = reinterpret_cast<int*>(scratch + 8 + 256);
+  for (int o = 32; o > 0; o >>= 1) {
+    kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o));
+    kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { cnt[tid >> 6] = kmax; cnt[4 + (tid >> 6)] = kmin; }
+  __syncthreads();
+  unsigned hi = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+  unsigned lo = min(min(cnt[4], cnt[5]), min(cnt[6], cnt[7]));
+  if (k == 1) {  // greedy argmax: the maximum, lowest index among equals
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j)
+      if (key[j] == hi && tid + 256 * j < V) best = min(best, tid + 256 * j);
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    __syncthreads();
+    if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)best;
+    __syncthreads();
+    if (tid == 0) {
+      out_i[0] = (int)min(min(cnt[0], cnt[1]), min(cnt[2], cnt[3]));
+      out_v[0] = funkey(hi);
+    }
+    return;
+  }
+  // largest T with count(key >= T) >= k   (count(key >= lo) = V >= k)
+  for (int it = 0; it < 32 && lo < hi; ++it) {
+    const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) c += key[j] >= mid;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __syncthreads();
+    if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)c;
+    __syncthreads();
+    const int total = (int)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+    if (total >= k) lo = mid; else hi = mid - 1u;
+  }
+  const unsigned T = lo;
+  __syncthreads();
+  if (tid == 0) { cnt[4] = 0u; cnt[5] = 0u; }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kRowRegs; ++j) {
+    const int i = tid + 256 * j;
+    if (i < V) {
+      if (key[j] > T) {
+        const unsigned q = atomicAdd(&cnt[4], 1u);
+        cv[q] = p[j]; ci[q] = i;
+      } else if (key[j] == T) {
+        atomicAdd(&cnt[5], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  const int ngt = (int)cnt[4], neq = (int)cnt[5], need = k - ngt;
+  __syncthreads();
+  if (neq == need) {
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) {
+      const int i = tid + 256 * j;
+      if (i < V && key[j] == T) {
+        const unsigned q = atomicAdd(&cnt[4], 1u);
+        cv[q] = p[j]; ci[q] = i;
+      }
+    }
+  } else {
+    // ties straddle the boundary: the `need` lowest indices win.  Picked one
+    // at a time by a block-min over the tied indices above the previous pick
+    // (rare: needs equal log-probs exactly at the k-th value).
+    int prev = -1;
+    for (int round = 0; round < need; ++round) {
+      int best = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < kRowRegs; ++j) {
+        const int i = tid + 256 * j;
+        if (i < V && key[j] == T && i > prev) best = min(best, i);
+      }
+      for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+      __syncthreads();
+      if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)best;
+      __syncthreads();
+      prev = (int)min(min(cnt[0], cnt[1]), min(cnt[2], cnt[3]));
+      if (tid == 0) { cv[ngt + round] = funkey(T); ci[ngt + round] = prev; }
+    }
+  }
+  __syncthreads();
+  int P = 64;
+  while (P < k) P <<= 1;
+  if (tid >= k && tid < P) { cv[tid] = -INFINITY; ci[tid] = 0x7fffffff; }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = tid ^ stride;
+      if (tid < P && partner > tid) {
+        const float av = cv[tid], bv = cv[partner];
+        const int ai = ci[tid], bi = ci[partner];
+        const bool a_first = av > bv || (av == bv && ai < bi);
+        const bool up = (tid & size) == 0;
+        if (up ? !a_first : a_first) {
+          cv[tid] = bv; ci[tid] = bi; cv[partner] = av; ci[partner] = ai;
+        }
+      }
+      __syncthreads();
+    }
+  if (tid < k) { out_v[tid] = cv[tid]; out_i[tid] = ci[tid]; }
+}
+
 // allennlp beam restriction: per neuron, top-`beam` of the beam_prev*beam
 // summed candidates; backpointer = flat index / beam (trunc).
 __global__ __launch_bounds__(256) void beam_merge_kernel(
@@ -822,6 +1014,15 @@ static int launch_row_select(const float* logits, const float* lm_logits,
                              const int64_t* last_tok, int stop, float* cand_v,
                              int* cand_i, float* pred_out, long pred_stride,
                              hipStream_t s) {
+  if (V <= kRowRegs * 256 && k <= 256 && (k <= 1 || k <= V)) {
+    // ties straddling the k-th value are resolved for up to 16 picks in the
+    // register kernel; larger tie groups are impossible for distinct logits
+    hipLaunchKernelGGL(row_select_reg_kernel, dim3(rows), dim3(256), 0, s,
+                       logits, lm_logits, lambda, V, k, last_tok, stop, cand_v,
+                       cand_i, pred_out, pred_stride);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t lds = row_select_lds(V);
   MILAN_REQUIRE(lds <= 160 * 1024, MILAN_ERR_SHAPE,
                 "vocab_size %d too large for the row-select kernel", V);
