@@ -101,6 +101,11 @@ def main():
                     help='neurons for the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-profile', action='store_true',
                     help='do not bracket GEMM launches with HIP events')
+    ap.add_argument('--pipeline', type=int, default=0,
+                    help='1: run the encoder of step i+1 on a second HIP stream '
+                    'while step i decodes (measured 2x SLOWER on MI355X: the '
+                    'decode loop\'s ~450 dependent launches each queue behind a '
+                    'full-chip conv grid); 0: strictly serial steps (default)')
     ap.add_argument('--from-host-steps', type=int, default=0,
                     help='also time this many steps fed from pinned host uint8 '
                     'tensors through the double-buffered ingest (PCIe-inclusive '
@@ -153,7 +158,18 @@ def main():
     if not args.no_profile:
         hip.profile_enable(True)
     t0 = time.perf_counter()
-    outs = [step(i) for i in range(args.steps)]
+    if args.pipeline and strategy != hip.GREEDY:
+        # encoder of step i+1 overlaps the decode loop of step i (two streams)
+        chunks = ((images[(i % n_steps_data) * args.chunk:
+                          (i % n_steps_data + 1) * args.chunk],
+                   masks[(i % n_steps_data) * args.chunk:
+                         (i % n_steps_data + 1) * args.chunk])
+                  for i in range(args.steps))
+        outs = list(ctx.describe_pipelined(chunks, strategy, args.length, beam,
+                                           False, args.temperature,
+                                           group_size=16))
+    else:
+        outs = [step(i) for i in range(args.steps)]
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = time.perf_counter() - t0
