@@ -165,6 +165,18 @@ int milan_describe(milan_ctx* ctx, const void* images, int image_dtype,
                    int32_t* out_len, void* workspace, size_t workspace_bytes,
                    milan_stream stream);
 
+/* hipGraph capture of the decode stage.  When enabled, milan_decode (and the
+ * decode half of milan_describe) records its launches -- the whole
+ * Decoder.forward search of src/milan/decoders.py:418-512 for one batch -- into
+ * a hipGraph the second time an identical call (same sizes AND same buffer
+ * pointers, same stream) is seen, and replays it with one hipGraphLaunch from
+ * then on.  Requires a non-default stream and caller-side buffer reuse;
+ * otherwise (or while milan_profile_enable is on) calls run as plain launches.
+ * milan_graph_stats reports how many graphs were captured / replayed. */
+int milan_set_graph_capture(milan_ctx* ctx, int enable);
+int milan_graph_stats(const milan_ctx* ctx, long long* captures,
+                      long long* replays);
+
 /* Arithmetic mode of every dense contraction (convs, Linear, LSTM gates).
  *   MILAN_PRECISION_F32       fp32-in / fp32-accumulate MFMA: bitwise an fmaf
  *                             chain, the reference's precision (default).

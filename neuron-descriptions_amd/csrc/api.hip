@@ -124,6 +124,8 @@ int milan_create(milan_ctx** out, int device, const milan_dims* dims) {
 void milan_destroy(milan_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  for (auto& g : c->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->owned) (void)hipFree(p);
   delete c;
 }
@@ -167,6 +169,88 @@ size_t milan_workspace_bytes(const milan_ctx* c, int max_neurons, int k,
   // + an internal features buffer for milan_describe + slack for alignment
   return (enc > dec ? enc : dec) +
          (size_t)max_neurons * k * c->d.feature_size * sizeof(float) + (1 << 16);
+}
+
+// Decoder.forward's decode stage behind a hipGraph: the ~450 launches of one
+// (n, beam, length, strategy) decode are captured from the stream once (second
+// time the same argument tuple -- pointers included -- is seen) and replayed
+// with a single hipGraphLaunch afterwards.  Needs a non-default stream and
+// pointer-stable buffers (the Python binding keeps them); falls back to direct
+// launches while profiling, on the legacy stream, or if capture fails.
+struct DecodeCall {
+  const float* features; int n, k, strategy, length, beam, mi; float temperature;
+  int group; int64_t* tokens; float* scores; float* predictions; float* attentions;
+  int64_t* beam_tokens; float* beam_scores; int32_t* out_len; void* ws;
+  size_t ws_bytes; hipStream_t stream; int precision;
+};
+
+static int decode_direct(milan_ctx* c, const DecodeCall& d) {
+  Arena a;
+  a.base = (char*)d.ws; a.size = d.ws_bytes; a.off = 0;
+  return decoder_decode(c, d.features, d.n, d.k, d.strategy, d.length, d.beam,
+                        d.mi, d.temperature, d.group, d.tokens, d.scores,
+                        d.predictions, d.attentions, d.beam_tokens, d.beam_scores,
+                        d.out_len, a, d.stream);
+}
+
+static int decode_maybe_graph(milan_ctx* c, const DecodeCall& d) {
+  if (!c->graph_capture || d.stream == nullptr || gemm_profile_active())
+    return decode_direct(c, d);
+  std::vector<char> key(sizeof(DecodeCall), 0);
+  {
+    DecodeCall z;
+    memset(&z, 0, sizeof(z));  // zero padding bytes before the field copy
+    z.features = d.features; z.n = d.n; z.k = d.k; z.strategy = d.strategy;
+    z.length = d.length; z.beam = d.beam; z.mi = d.mi;
+    z.temperature = d.temperature; z.group = d.group; z.tokens = d.tokens;
+    z.scores = d.scores; z.predictions = d.predictions;
+    z.attentions = d.attentions; z.beam_tokens = d.beam_tokens;
+    z.beam_scores = d.beam_scores; z.out_len = d.out_len; z.ws = d.ws;
+    z.ws_bytes = d.ws_bytes; z.stream = d.stream; z.precision = c->precision;
+    memcpy(key.data(), &z, sizeof(z));
+  }
+  milan_ctx::GraphEntry* e = nullptr;
+  for (auto& g : c->graphs)
+    if (g.key == key) { e = &g; break; }
+  if (e && e->exec) {
+    MILAN_CHECK_HIP(hipGraphLaunch(e->exec, d.stream));
+    ++c->graph_replays;
+    return 0;
+  }
+  if (!e) {  // first sight: run directly (also sets kernel attributes)
+    if (c->graphs.size() >= 16) {
+      if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec);
+      c->graphs.erase(c->graphs.begin());
+    }
+    milan_ctx::GraphEntry ne;
+    ne.key = key; ne.seen = 1;
+    c->graphs.push_back(ne);
+    return decode_direct(c, d);
+  }
+  // second sight: capture, instantiate, launch
+  hipGraph_t graph = nullptr;
+  hipError_t err = hipStreamBeginCapture(d.stream, hipStreamCaptureModeRelaxed);
+  if (err != hipSuccess) { (void)hipGetLastError(); return decode_direct(c, d); }
+  const int r = decode_direct(c, d);
+  err = hipStreamEndCapture(d.stream, &graph);
+  if (r != 0 || err != hipSuccess || graph == nullptr) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    if (r != 0) return r;
+    return decode_direct(c, d);
+  }
+  hipGraphExec_t exec = nullptr;
+  err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (err != hipSuccess || exec == nullptr) {
+    (void)hipGetLastError();
+    return decode_direct(c, d);
+  }
+  e->exec = exec;
+  ++c->graph_captures;
+  MILAN_CHECK_HIP(hipGraphLaunch(exec, d.stream));
+  ++c->graph_replays;
+  return 0;
 }
 
 static int make_arena(void* ws, size_t bytes, Arena* a) {
@@ -226,10 +310,29 @@ int milan_decode(milan_ctx* c, const float* features, int n, int k, int strategy
   MILAN_REQUIRE(c && features, MILAN_ERR_ARG, "milan_decode: null argument");
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
-  return decoder_decode(c, features, n, k, strategy, length, beam_size, mi,
-                        temperature, group_size, tokens, scores, predictions,
-                        attentions, beam_tokens, beam_scores, out_len, a,
-                        (hipStream_t)stream);
+  DecodeCall d{features, n, k, strategy, length, beam_size, mi, temperature,
+               group_size, tokens, scores, predictions, attentions, beam_tokens,
+               beam_scores, out_len, workspace, workspace_bytes,
+               (hipStream_t)stream, c->precision};
+  return decode_maybe_graph(c, d);
+}
+
+int milan_set_graph_capture(milan_ctx* c, int enable) {
+  MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
+  c->graph_capture = enable != 0;
+  if (!enable) {
+    for (auto& g : c->graphs)
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+  }
+  return 0;
+}
+
+int milan_graph_stats(const milan_ctx* c, long long* captures, long long* replays) {
+  MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
+  if (captures) *captures = c->graph_captures;
+  if (replays) *replays = c->graph_replays;
+  return 0;
 }
 
 int milan_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
@@ -339,12 +442,11 @@ int milan_describe(milan_ctx* c, const void* images, int image_dtype,
   enc.base = a.base + a.off; enc.size = a.size - a.off; enc.off = 0;
   MILAN_TRY(encoder_run(c, images, image_dtype, masks, mask_dtype, n * k, height,
                         width, feats, enc, (hipStream_t)stream));
-  Arena dec = enc;
-  dec.off = 0;
-  return decoder_decode(c, feats, n, k, strategy, length, beam_size, mi,
-                        temperature, group_size, tokens, scores, predictions,
-                        attentions, beam_tokens, beam_scores, out_len, dec,
-                        (hipStream_t)stream);
+  DecodeCall d{feats, n, k, strategy, length, beam_size, mi, temperature,
+               group_size, tokens, scores, predictions, attentions, beam_tokens,
+               beam_scores, out_len, enc.base, enc.size, (hipStream_t)stream,
+               c->precision};
+  return decode_maybe_graph(c, d);
 }
 
 }  // extern "C"

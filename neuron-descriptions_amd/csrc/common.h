@@ -82,6 +82,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s);
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
                         long rows, int K, float scale, hipStream_t s);
 int gemm_profile_enable(int enable);
+bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, long long* launches);
 
 inline GemmArgs linear_args(const float* A, long lda, const float* W,
@@ -153,6 +154,11 @@ struct milan_ctx {
   milan_dims d{};
   bool finalized = false;
   int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16
+  // hipGraph cache of whole decode passes (milan_set_graph_capture)
+  int graph_capture = 0;
+  struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int seen = 0; };
+  std::vector<GraphEntry> graphs;
+  long graph_replays = 0, graph_captures = 0;
   float* scratch = nullptr;   // per-call split-conversion scratch (workspace)
   size_t scratch_floats = 0;
   std::map<std::string, milan::Tensor> raw;  // named reference tensors

@@ -800,6 +800,8 @@ int gemm_profile_enable(int enable) {
   return 0;
 }
 
+bool gemm_profile_active() { return g_prof.on; }
+
 int gemm_profile_read(double* ms, double* flops, long long* launches) {
   MILAN_CHECK_HIP(hipDeviceSynchronize());
   double total = 0.0;

@@ -137,6 +137,9 @@ class Decoder(nn.Module):
         # faster); see DESIGN.md section 4.2.  MILAN_PRECISION sets the default.
         import os
         self.precision = os.environ.get('MILAN_PRECISION', 'f32')
+        # replay each distinct decode pass from a captured hipGraph (helps
+        # only launch-bound small batches; see hip.Context.enable_graphs)
+        self.use_graphs = os.environ.get('MILAN_GRAPHS', '0') == '1'
 
         f = torch.float32
         fs, hs, es, v = (self.feature_size, hidden_size, embedding_size,
@@ -203,6 +206,8 @@ class Decoder(nn.Module):
             self._ctx_key = key
         if self._ctx.precision != self.precision:
             self._ctx.set_precision(self.precision)
+        if bool(getattr(self._ctx, '_graphs', False)) != bool(self.use_graphs):
+            self._ctx.enable_graphs(self.use_graphs)
         return self._ctx
 
     # -- forward -------------------------------------------------------------------

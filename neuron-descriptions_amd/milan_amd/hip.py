@@ -81,6 +81,11 @@ SIGNATURES = {
         _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P,
         _P, _P, _P, _P, _P, _P, _SZ, _P
     ]),
+    'milan_set_graph_capture': (_I, [_P, _I]),
+    'milan_graph_stats': (_I, [
+        _P, ctypes.POINTER(ctypes.c_longlong),
+        ctypes.POINTER(ctypes.c_longlong)
+    ]),
     'milan_set_precision': (_I, [_P, _I]),
     'milan_get_precision': (_I, [_P]),
     'milan_profile_enable': (_I, [_I]),
@@ -189,6 +194,34 @@ class Context:
         default = os.environ.get('MILAN_PRECISION')
         if default:
             self.set_precision(default)
+
+    # -- hipGraph replay of the decode stage ------------------------------------
+    def enable_graphs(self, enable: bool = True) -> None:
+        """Capture each distinct decode pass into a hipGraph and replay it.
+
+        Pays off for small interactive batches, where the ~450 launches of a
+        beam search are latency-bound.  Needs pointer-stable buffers and a
+        non-default stream, so outputs then live in per-shape pools (callers get
+        clones) and the calls run on a private stream that is joined with the
+        caller's stream before and after.
+        """
+        _check(self.lib.milan_set_graph_capture(self._h, int(enable)))
+        self._graphs = bool(enable)
+        if enable and getattr(self, '_gstream', None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+            self._pool = {}
+
+    def graph_stats(self):
+        cap, rep = ctypes.c_longlong(), ctypes.c_longlong()
+        _check(self.lib.milan_graph_stats(self._h, ctypes.byref(cap),
+                                          ctypes.byref(rep)))
+        return cap.value, rep.value
+
+    def _pooled(self, key, make):
+        buf = self._pool.get(key)
+        if buf is None:
+            self._pool[key] = buf = make()
+        return buf
 
     def set_precision(self, precision) -> None:
         """'f32' (exact fp32 MFMA, default) or 'split_f16' (3xf16 MFMA)."""
@@ -330,6 +363,9 @@ class Context:
                want_full: bool = True):
         n, k, _ = features.shape
         features = _dev(features, self.device, torch.float32)
+        if getattr(self, '_graphs', False):
+            return self._decode_graphed(features, strategy, length, beam, mi,
+                                        temperature, group_size, want_full)
         out = self._alloc_outputs(n, k, strategy, length, beam, want_full)
         groups = (n + group_size - 1) // group_size if group_size > 0 else 1
         out['out_len'] = torch.full((groups,),
@@ -347,6 +383,43 @@ class Context:
                     _ptr(out['beam_tokens']), _ptr(out['beam_scores']),
                     out['out_len'].data_ptr(), ws.data_ptr(), ws.numel(),
                     _stream(self.device)))
+        return out
+
+    def _decode_graphed(self, features, strategy, length, beam, mi, temperature,
+                        group_size, want_full):
+        n, k, fsz = features.shape
+        sig = (n, k, strategy, length, beam, bool(mi), group_size, want_full)
+        groups = (n + group_size - 1) // group_size if group_size > 0 else 1
+
+        def make():
+            out = self._alloc_outputs(n, k, strategy, length, beam, want_full)
+            out['out_len'] = torch.empty(groups, dtype=torch.int32,
+                                         device=self.device)
+            out['_features'] = torch.empty(n, k, fsz, device=self.device)
+            return out
+
+        cur = torch.cuda.current_stream(self.device)
+        gs = self._gstream
+        gs.wait_stream(cur)
+        with torch.cuda.device(self.device), torch.cuda.stream(gs):
+            pool = self._pooled(sig, make)
+            ws = self.workspace(n, k, 0, beam, length)
+            pool['_features'].copy_(features)
+            _check(
+                self.lib.milan_decode(
+                    self._h, pool['_features'].data_ptr(), n, k, strategy,
+                    length, beam, int(bool(mi)), float(temperature), group_size,
+                    pool['tokens'].data_ptr(), pool['scores'].data_ptr(),
+                    _ptr(pool['predictions']), _ptr(pool['attentions']),
+                    _ptr(pool['beam_tokens']), _ptr(pool['beam_scores']),
+                    pool['out_len'].data_ptr(), ws.data_ptr(), ws.numel(),
+                    gs.cuda_stream))
+            out = {key: (v.clone() if isinstance(v, torch.Tensor) else v)
+                   for key, v in pool.items() if key != '_features'}
+        cur.wait_stream(gs)
+        for v in out.values():
+            if isinstance(v, torch.Tensor):
+                v.record_stream(cur)
         return out
 
     def lm_score(self, seqs: torch.Tensor) -> torch.Tensor:
