@@ -71,6 +71,12 @@ struct GemmArgs {
   int aux_split;      // 1: aux is in split format
   float acc_scale;    // accumulators are multiplied by this (1 / weight scale)
   int out_mode;       // filled by the launcher (OUT_*)
+  // optional second operand source (split16 kernels only): k >= K1 reads a
+  // 1x1 / stride `stride2` convolution input A2 (H2 x W2d pixels, no padding).
+  // Used to fold a bottleneck's downsample conv into its c3 (K-concatenation).
+  const float* A2;
+  int K1, H2, W2d, stride2;
+  long a2_pix_stride, a2_img_stride;
   int debug;          // ablation switches for timing experiments (0 in production)
   int tile_hint;      // 0 auto, 1 force 256x128x3-stage, 2 force 128x128x2-stage
 };
@@ -111,6 +117,7 @@ struct ConvW {
 };
 struct Bottleneck {
   ConvW c1, c2, c3, down;
+  ConvW c3d;  // [c3 | downsample] concatenated along K (split mode fusion)
   bool has_down = false;
 };
 struct LinearW {

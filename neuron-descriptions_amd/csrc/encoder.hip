@@ -105,6 +105,47 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
   return 0;
 }
 
+// [c3 | downsample] along K: out = relu(W3 t2 + Wd x_s + (b3 + bd)), one GEMM
+// instead of two plus a round trip of the downsample output through HBM.
+__global__ void concat_k_kernel(const float* __restrict__ a, int ka,
+                                const float* __restrict__ b, int kb, int n,
+                                float* __restrict__ out) {
+  const int kt = ka + kb;
+  const long total = (long)n * kt;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int r = idx / kt, col = idx - (long)r * kt;
+    out[idx] = col < ka ? a[(long)r * ka + col] : b[(long)r * kb + (col - ka)];
+  }
+}
+__global__ void add2_kernel(const float* a, const float* b, int n, float* o) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+static int fuse_c3_down(milan_ctx* c, Bottleneck* b, hipStream_t s) {
+  const ConvW &c3 = b->c3, &dn = b->down;
+  if (c3.K != c3.Kp || dn.K != dn.Kp || c3.K % 32 || dn.K % 32 ||
+      c3.cout != dn.cout || !c3.ws || !dn.ws)
+    return 0;  // shapes the fused path does not cover: keep them separate
+  ConvW f;
+  f.cout = c3.cout; f.cin = c3.cin; f.cin_real = c3.cin_real;
+  f.kh = f.kw = 1; f.stride = 1; f.pad = 0;
+  f.K = f.Kp = c3.K + dn.K;
+  MILAN_TRY(dev_alloc(c, (void**)&f.w, sizeof(float) * (size_t)f.cout * f.Kp));
+  MILAN_TRY(dev_alloc(c, (void**)&f.bias, sizeof(float) * f.cout));
+  const long total = (long)f.cout * f.Kp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(concat_k_kernel, dim3(blocks), dim3(256), 0, s, c3.w, c3.K,
+                     dn.w, dn.K, f.cout, f.w);
+  hipLaunchKernelGGL(add2_kernel, dim3((f.cout + 255) / 256), dim3(256), 0, s,
+                     c3.bias, dn.bias, f.cout, f.bias);
+  MILAN_CHECK_HIP(hipGetLastError());
+  MILAN_TRY(make_split_weight(c, f.w, f.cout, f.Kp, &f.ws, &f.ws_inv, s));
+  b->c3d = f;
+  return 0;
+}
+
 int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
                     float* wp, hipStream_t s) {
   const int cinp = (cin + 3) / 4 * 4;
@@ -150,9 +191,11 @@ int encoder_finalize(milan_ctx* c, hipStream_t s) {
       b.has_down = find(c, q + "downsample.0.weight") != nullptr;
       MILAN_REQUIRE(b.has_down == (bi == 0), MILAN_ERR_STATE,
                     "unexpected downsample layout at %s", q.c_str());
-      if (b.has_down)
+      if (b.has_down) {
         MILAN_TRY(pack_conv(c, q + "downsample.0", q + "downsample.1", stride,
                             0, &b.down, s));
+        MILAN_TRY(fuse_c3_down(c, &b, s));
+      }
       c->blocks[li].push_back(b);
     }
   }
@@ -629,6 +672,25 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                               nullptr, c->zero, &h2, &w2, split);
       MILAN_TRY(launch_gemm(g2, s));
       const float* identity = x;
+      if (b.has_down && split && b.c3d.ws && (long)n * h2 * w2 >= 256 &&
+          b.c3d.cout > 64) {
+        // c3 and the downsample as ONE GEMM over [t2 | x(strided)]
+        int h3, w3;
+        GemmArgs g3 = conv_args(b.c3d, pl.t2, n, h2, w2, y, EPI_BIAS_RELU,
+                                nullptr, c->zero, &h3, &w3, true);
+        g3.Cin = b.c3.cin;              // geometry of source 1 (t2)
+        g3.a_pix_stride = b.c3.cin;
+        g3.a_img_stride = (long)h2 * w2 * b.c3.cin;
+        g3.A2 = x; g3.K1 = b.c3.K; g3.H2 = h; g3.W2d = w;
+        g3.stride2 = b.down.stride;
+        g3.a2_pix_stride = b.down.cin;
+        g3.a2_img_stride = (long)h * w * b.down.cin;
+        g3.flop_k = b.c3.K + b.down.K;
+        MILAN_TRY(launch_gemm(g3, s));
+        float* tmp = x; x = y; y = tmp;
+        h = h3; w = w3;
+        continue;
+      }
       if (b.has_down) {
         int hd, wdn;
         GemmArgs gd = conv_args(b.down, x, n, h, w, pl.ds, EPI_BIAS, nullptr,

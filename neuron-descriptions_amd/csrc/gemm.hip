@@ -540,6 +540,8 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   const int lrow = tid >> 2;                        // 0..LROWS-1
   const int kc = (tid & 3) ^ ((tid >> 4) & 3);      // (row>>2)&3 == (tid>>4)&3
   RowInfo ra[A_ITERS];
+  const float* ra2[A_ITERS];
+  const int k1 = g.A2 ? g.K1 : 0x7fffffff;
   const int HoWo = g.Ho * g.Wo;
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
@@ -555,6 +557,12 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
     ra[it].base = g.A + (long)img * g.a_img_stride +
                   ((long)ra[it].hi0 * g.Wd + ra[it].wi0) * g.a_pix_stride +
                   kc * 4;
+    // second source (1x1, stride2, always in bounds), or the same pointer
+    ra2[it] = g.A2 ? g.A2 + (long)img * g.a2_img_stride +
+                         ((long)(ho * g.stride2) * g.W2d + wo * g.stride2) *
+                             g.a2_pix_stride +
+                         kc * 4 - g.K1
+                   : ra[it].base;
   }
   const float* rb[B_ITERS];
 #pragma unroll
@@ -592,6 +600,7 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
       const int hi = ra[it].hi0 + is_kh, wi = ra[it].wi0 + is_kw;
       const bool inb = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.Wd;
       const float* src = inb ? ra[it].base + toff : g.zero;
+      if (is_kt * BK >= k1) src = ra2[it] + is_kt * BK;  // wave-uniform
       float* adst = As + buf * (BM * BK) + wave * (16 * BK) + it * (LROWS * BK);
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
                                        (LDS_AS void*)adst, 16, 0, 0);
@@ -886,6 +895,10 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
                          ((g.ldaux % 4 == 0) && aligned16(g.aux)));
     g.out_mode = vec_ok ? OUT_VEC4 : OUT_SCALAR;
   }
+  MILAN_REQUIRE(g.A2 == nullptr || (g.a_split && g.N > 64 && g.M >= 256 &&
+                                    g.KH == 1 && g.KW == 1 && g.K1 % 16 == 0 &&
+                                    g.tile_hint == 0),
+                MILAN_ERR_SHAPE, "gemm: two-source A needs the split16 kernels");
   if (g.a_split) {
     MILAN_REQUIRE(cin32, MILAN_ERR_SHAPE,
                   "gemm: split-f16 operands need Cin %% 32 == 0 (Cin=%d)", g.Cin);
