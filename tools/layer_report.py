@@ -1,6 +1,6 @@
 """Per-layer GEMM throughput from a rocprofv3 rocpd database of bench.py.
 
-usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3]
+usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3] [fused_ds=0|1]
 Maps the igemm dispatches of one hot-path pass onto the ResNet-101 layer list
 (launch order is deterministic) and prints time / algorithmic TFLOP/s per
 layer group, then the decoder+LM GEMM total.
@@ -14,6 +14,7 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
     passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    fused = len(sys.argv) > 4 and sys.argv[4] == '1'  # split mode: ds folded into c3
     rows = db.execute(
         "select name, start, end-start, grid_x from kernels where name like "
         "'%igemm%' order by start").fetchall()
@@ -21,10 +22,11 @@ def main():
     rows = rows[per * (passes - 1):]
     layers = []
 
-    def conv(name, h, cin, cout, k, s):
+    def conv(name, h, cin, cout, k, s, extra_k=0):
         ho = (h + 2 * (k // 2) - k) // s + 1
         m = n * ho * ho
-        layers.append((name, m, cout, k * k * cin, 2 * m * cout * k * k * cin))
+        kk = k * k * cin + extra_k
+        layers.append((name, m, cout, kk, 2 * m * cout * kk))
         return ho
 
     conv('stem', 224, 3, 64, 7, 2)
@@ -35,9 +37,12 @@ def main():
             s = 2 if (bi == 0 and li > 0) else 1
             conv(f'l{li+1}.{bi}.c1', h, inp, pl, 1, 1)
             h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
-            if bi == 0:
+            if bi == 0 and not fused:
                 conv(f'l{li+1}.{bi}.ds', h, inp, pl * 4, 1, s)
-            conv(f'l{li+1}.{bi}.c3', h2, pl, pl * 4, 1, 1)
+            if bi == 0 and fused:
+                conv(f'l{li+1}.{bi}.c3+ds', h2, pl, pl * 4, 1, 1, extra_k=inp)
+            else:
+                conv(f'l{li+1}.{bi}.c3', h2, pl, pl * 4, 1, 1)
             h, inp = h2, pl * 4
     agg, tot_t, tot_f = {}, 0, 0
     for (name, m, nn, k, fl), (_, _, du, _) in zip(layers, rows):
