@@ -77,7 +77,12 @@ struct GemmArgs {
   const float* A2;
   int K1, H2, W2d, stride2;
   long a2_pix_stride, a2_img_stride;
-  int debug;          // ablation switches for timing experiments (0 in production)
+  // anisotropic geometry (general igemm path only): when aniso != 0 the
+  // horizontal stride / padding are stride_w / pad_w instead of stride / pad.
+  // Used by the pixel-pair stem (encoder.hip).
+  int aniso, stride_w, pad_w;
+  int debug;          // MILAN_ABLATE timing experiments (0 in production): 1 no MFMA,
+                      // 2 no DMA (igemm_kernel); 4 epilogue only, 8 main loop only (split16)
   int tile_hint;      // 0 auto, 1 force 256x128x3-stage, 2 force 128x128x2-stage
 };
 
@@ -174,6 +179,7 @@ struct milan_ctx {
   float* zero = nullptr;
   // encoder
   milan::ConvW stem;
+  milan::ConvW stem_pair;  // split-f16 stem over pixel-pair groups (encoder.hip)
   float *bn1_scale = nullptr, *bn1_shift = nullptr;
   std::vector<milan::Bottleneck> blocks[4];
   float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};

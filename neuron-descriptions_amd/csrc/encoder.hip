@@ -159,6 +159,42 @@ int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
   return 0;
 }
 
+// Pixel-pair stem (split-f16 mode).  A 3-channel pixel would waste 5 of the 8
+// slots of a split-format group, so a group holds TWO horizontally adjacent
+// pixels (x = 2p-1, 2p; RGB0 RGB0).  With stride 2 / pad 3 the 7 taps of one
+// kernel row of output column wo are exactly groups wo-1 .. wo+2 (the 8th tap
+// has zero weight): the 7x7/2 stem becomes a KH=7 x KW=4 convolution over
+// groups with horizontal stride 1 / pad 1, K = 7*4*8 = 224 slots instead of
+// the 392 a Cin=8 padding would need.  Weights: k = (kh*4 + j)*8 + e with tap
+// t = 2j + e/4, channel e%4.
+__global__ void pack_stem_pairs_kernel(const float* __restrict__ w, int cout,
+                                       float* __restrict__ wp) {
+  const int total = cout * 224;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += gridDim.x * blockDim.x) {
+    const int o = idx / 224, k = idx - o * 224;
+    const int e = k & 7, j = (k >> 3) & 3, kh = k >> 5;
+    const int t = 2 * j + (e >> 2), ch = e & 3;
+    wp[idx] = (t < 7 && ch < 3) ? w[((o * 3 + ch) * 7 + kh) * 7 + t] : 0.f;
+  }
+}
+
+static int pack_stem_pairs(milan_ctx* c, const Tensor* w, hipStream_t s) {
+  ConvW& f = c->stem_pair;
+  f = ConvW();
+  if (w->shape[1] != 3 || w->shape[2] != 7 || w->shape[3] != 7 ||
+      w->shape[0] > 64 || w->shape[0] % 8)
+    return 0;  // not the torchvision stem: split mode keeps the fp32 stem
+  f.cout = (int)w->shape[0];
+  f.cin = 8; f.cin_real = 3; f.kh = 7; f.kw = 4; f.stride = 2; f.pad = 3;
+  f.K = f.Kp = 224;
+  MILAN_TRY(dev_alloc(c, (void**)&f.w, sizeof(float) * (size_t)f.cout * f.Kp));
+  hipLaunchKernelGGL(pack_stem_pairs_kernel, dim3((f.cout * 224 + 255) / 256),
+                     dim3(256), 0, s, w->dev, f.cout, f.w);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return make_split_weight(c, f.w, f.cout, f.Kp, &f.ws, &f.ws_inv, s);
+}
+
 int encoder_finalize(milan_ctx* c, hipStream_t s) {
   const std::string p = "encoder.encoder.model.";
   if (!find(c, p + "conv1.weight")) return 0;  // decoder-only context
@@ -166,6 +202,7 @@ int encoder_finalize(milan_ctx* c, hipStream_t s) {
   MILAN_REQUIRE(c->stem.cout == c->d.trunk_width, MILAN_ERR_SHAPE,
                 "stem width %d != dims.trunk_width %d", c->stem.cout,
                 c->d.trunk_width);
+  MILAN_TRY(pack_stem_pairs(c, find(c, p + "conv1.weight"), s));
   {
     const Tensor *tg = find(c, p + "bn1.weight"), *tb = find(c, p + "bn1.bias"),
                  *tm = find(c, p + "bn1.running_mean"),
@@ -221,6 +258,9 @@ __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
                                   int hw, float m0, float m1, float m2,
                                   float s0, float s1, float s2,
                                   float4* __restrict__ out) {
+  // the byte->float product is rounded on its own, as in the reference: no
+  // contraction into the mean subtraction
+#pragma clang fp contract(off)
   const float inv255 = (float)(1.0 / 255.0);
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n_pix_total;
        p += (long)gridDim.x * blockDim.x) {
@@ -290,6 +330,49 @@ __device__ inline void enc_split8(const float* v, f32x4_t* hi_out,
   *lo_out = __builtin_bit_cast(f32x4_t, l);
 }
 
+// NCHW u8/f32 -> normalised pixel-pair groups in split-f16 format:
+// out[img][y][p] = split8(RGB0 of x=2p-1, RGB0 of x=2p), p in [0, G), zeros
+// outside the image (see pack_stem_pairs_kernel).
+template <typename T>
+__global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups,
+                                        int H, int W, int G, float m0, float m1,
+                                        float m2, float s0, float s1, float s2,
+                                        float* __restrict__ out) {
+#pragma clang fp contract(off)  // see preprocess_kernel
+  const float inv255 = (float)(1.0 / 255.0);
+  const long hw = (long)H * W;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n_groups;
+       q += (long)gridDim.x * blockDim.x) {
+    const int p = q % G;
+    const long row = q / G;            // img * H + y
+    const long n = row / H;
+    const int y = row - n * H;
+    const T* base = img + n * 3 * hw + (long)y * W;
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int x = 2 * p - 1 + h;
+      float a = 0.f, b = 0.f, cc = 0.f;
+      if (x >= 0 && x < W) {
+        if constexpr (sizeof(T) == 1) {
+          a = (float)base[x] * inv255;
+          b = (float)base[hw + x] * inv255;
+          cc = (float)base[2 * hw + x] * inv255;
+        } else {
+          a = base[x]; b = base[hw + x]; cc = base[2 * hw + x];
+        }
+        a = (a - m0) / s0; b = (b - m1) / s1; cc = (cc - m2) / s2;
+      }
+      v[4 * h] = a; v[4 * h + 1] = b; v[4 * h + 2] = cc; v[4 * h + 3] = 0.f;
+    }
+    f32x4_t hi, lo;
+    enc_split8(v, &hi, &lo);
+    f32x4_t* o = reinterpret_cast<f32x4_t*>(out + q * 8);
+    o[0] = hi;
+    o[1] = lo;
+  }
+}
+
 // Same, 8 channels per thread, output in split-f16 format (gemm.hip).
 __global__ void bn_relu_maxpool_split_kernel(const float* __restrict__ x, int n,
                                              int H, int W, int C, int Ho, int Wo,
@@ -355,6 +438,9 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
     const T* __restrict__ masks, int H, int W, Levels lv,
     int* __restrict__ list_idx, float* __restrict__ list_w,
     int* __restrict__ list_n) {
+  // every product/sum below is rounded as written (ATen's scalar formula), the
+  // same for the uint8 and float instantiations
+#pragma clang fp contract(off)
   __shared__ float wts[kMaxLevelPixels];
   __shared__ float red_sum[4], red_max[4];
   const int img = blockIdx.x, l = blockIdx.y;
@@ -493,7 +579,8 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   for (int l = 0; l < 5; ++l) { lv.off[l] = off; off += (long)lv.h[l] * lv.w[l]; }
   lv.per_image = off;
   const size_t p0 = (size_t)n * pl->hp * pl->wp;  // pixels at layer1 resolution
-  pl->in4 = a.get<float>((size_t)n * H * W * 4);
+  // NHWC4 fp32, or (W+2)/2 pixel-pair groups of 8 slots per row (split stem)
+  pl->in4 = a.get<float>((size_t)n * H * (W + 2) * 4);
   pl->raw = a.get<float>((size_t)n * pl->h1 * pl->w1 * wd);
   pl->x0 = a.get<float>(p0 * wd * 4);
   pl->x1 = a.get<float>(p0 * wd * 4);
@@ -601,28 +688,38 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                        pl.list_n);
   MILAN_CHECK_HIP(hipGetLastError());
 
-  // 2. images -> normalised NHWC4
-  {
-    const long np = (long)n * H * W;
-    const int blocks = (int)((np + 255) / 256 < 8192 ? (np + 255) / 256 : 8192);
-    if (image_dtype == MILAN_DTYPE_U8)
-      hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
-                         s, (const uint8_t*)images, np, H * W, c->mean[0],
-                         c->mean[1], c->mean[2], c->stdv[0], c->stdv[1],
-                         c->stdv[2], (float4*)pl.in4);
-    else
-      hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
-                         (const float*)images, np, H * W, c->mean[0], c->mean[1],
-                         c->mean[2], c->stdv[0], c->stdv[1], c->stdv[2],
-                         (float4*)pl.in4);
-    MILAN_CHECK_HIP(hipGetLastError());
-  }
-
   // split-f16 mode needs every bottleneck conv to have a split weight copy
   bool split = c->precision == MILAN_PRECISION_SPLIT_F16 && wd % 8 == 0;
   for (int li = 0; li < 4 && split; ++li)
     for (const Bottleneck& b : c->blocks[li])
       split = split && b.c1.ws && b.c2.ws && b.c3.ws && (!b.has_down || b.down.ws);
+  const bool pair_stem = split && c->stem_pair.ws != nullptr;
+  const int G = (W + 2) / 2;  // pixel-pair groups per image row
+
+  // 2. images -> normalised NHWC4 (fp32 stem) or pixel-pair groups (split stem)
+  {
+    const long np = pair_stem ? (long)n * H * G : (long)n * H * W;
+    const int blocks = (int)((np + 255) / 256 < 8192 ? (np + 255) / 256 : 8192);
+    const float m0 = c->mean[0], m1 = c->mean[1], m2 = c->mean[2];
+    const float s0 = c->stdv[0], s1 = c->stdv[1], s2 = c->stdv[2];
+    if (pair_stem && image_dtype == MILAN_DTYPE_U8)
+      hipLaunchKernelGGL(preprocess_pairs_kernel<uint8_t>, dim3(blocks),
+                         dim3(256), 0, s, (const uint8_t*)images, np, H, W, G,
+                         m0, m1, m2, s0, s1, s2, pl.in4);
+    else if (pair_stem)
+      hipLaunchKernelGGL(preprocess_pairs_kernel<float>, dim3(blocks), dim3(256),
+                         0, s, (const float*)images, np, H, W, G, m0, m1, m2, s0,
+                         s1, s2, pl.in4);
+    else if (image_dtype == MILAN_DTYPE_U8)
+      hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
+                         s, (const uint8_t*)images, np, H * W, m0, m1, m2, s0, s1,
+                         s2, (float4*)pl.in4);
+    else
+      hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
+                         (const float*)images, np, H * W, m0, m1, m2, s0, s1, s2,
+                         (float4*)pl.in4);
+    MILAN_CHECK_HIP(hipGetLastError());
+  }
 
   auto pool = [&](const float* tap, int level, int C, int col_off) -> int {
     const int P = pl.lv.h[level] * pl.lv.w[level];
@@ -643,6 +740,15 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   {
     GemmArgs g = conv_args(c->stem, pl.in4, n, H, W, pl.raw, EPI_BIAS, nullptr,
                            c->zero, &ho, &wo);
+    if (pair_stem) {
+      // KH=7 x KW=4 over pixel-pair groups, horizontal stride 1 / pad 1
+      g = conv_args(c->stem_pair, pl.in4, n, H, G, pl.raw, EPI_BIAS, nullptr,
+                    c->zero, &ho, &wo, true);
+      g.Ho = ho = pl.h1; g.Wo = wo = pl.w1;
+      g.M = n * ho * wo;
+      g.aniso = 1; g.stride_w = 1; g.pad_w = 1;
+      g.out_split = 0;  // the raw fp32 output is pyramid tap 0
+    }
     MILAN_TRY(launch_gemm(g, s));
     MILAN_TRY(pool(pl.raw, 0, wd, 0));
     const long total = (long)n * pl.hp * pl.wp * (wd / (split ? 8 : 4));

@@ -45,6 +45,10 @@
 #include <utility>
 #include <vector>
 
+#ifndef MILAN_ABLATE_BUILD
+#define MILAN_ABLATE_BUILD 0
+#endif
+
 namespace milan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -165,8 +169,32 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
+    // Residual groups are fetched one row-tile ahead, before any store of the
+    // current one: C and aux are not provably distinct, so without the explicit
+    // early loads every load would wait behind the previous store and the
+    // epilogue would pay one HBM round trip per 8 rows.
+    constexpr bool RES = (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD);
+    f32x4 res[RES ? 2 : 1][4][2];
+    auto load_res = [&](int i, f32x4 (&r)[4][2]) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = row0 + i * 32 + it * 8 + (lane >> 3);
+        if (m < g.M && n_ok) {
+          const float* ap = g.aux + (long)m * g.ldaux + n;
+          r[it][0] = *reinterpret_cast<const f32x4*>(ap);
+          r[it][1] = *reinterpret_cast<const f32x4*>(ap + 4);
+        } else {
+          r[it][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+          r[it][1] = r[it][0];
+        }
+      }
+    };
+    if constexpr (RES) load_res(0, res[0]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      if constexpr (RES) {
+        if (i + 1 < TM) load_res(i + 1, res[(i + 1) & 1]);
+      }
       to_stage(i);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -183,11 +211,9 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
             v[e] = v0[e] + bias8[e];
             v[4 + e] = v1[e] + bias8[4 + e];
           }
-          if constexpr (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD) {
-            const float* ap = g.aux + (long)m * g.ldaux + n;
+          if constexpr (RES) {
             float a[8];
-            join8(*reinterpret_cast<const f32x4*>(ap),
-                  *reinterpret_cast<const f32x4*>(ap + 4), a);
+            join8(res[i & 1][it][0], res[i & 1][it][1], a);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a[e];
           }
@@ -306,7 +332,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_kernel(
     const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
     ra[it].base = g.A + (long)img * g.a_img_stride;
     ra[it].hi0 = ho * g.stride - g.pad;
-    ra[it].wi0 = wo * g.stride - g.pad;
+    ra[it].wi0 = g.aniso ? wo * g.stride_w - g.pad_w : wo * g.stride - g.pad;
   }
   const float* rb[B_ITERS];
 #pragma unroll
@@ -593,7 +619,13 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   // slots nobody will consume again, so that every iteration issues exactly
   // LOADS pieces (constant vmcnt counts, branch-free loop body that the
   // scheduler can interleave with the MFMAs).
+  // timing experiments (-DMILAN_ABLATE_BUILD=1 + MILAN_ABLATE=bits); compiled out
+  // of the production library
+  const bool abl_dma = MILAN_ABLATE_BUILD && (g.debug & 16);
+  const bool abl_bar = MILAN_ABLATE_BUILD && (g.debug & 32);
+  const bool abl_mfma = MILAN_ABLATE_BUILD && (g.debug & 64);
   auto issue_piece = [&](int buf, int piece) {
+    if (abl_dma) { if (piece == LOADS - 1) advance_tap(); return; }
     if (piece < A_ITERS) {
       const int it = piece;
       const long toff = ((long)is_kh * g.Wd + is_kw) * g.a_pix_stride + is_cin0;
@@ -707,13 +739,18 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
   __builtin_amdgcn_s_barrier();
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk_run = (MILAN_ABLATE_BUILD && (g.debug & 4)) ? 0 : nk;  // epilogue only
+  for (int kt = 0; kt < nk_run; ++kt) {
     int nxt = cur + AHEAD;
     nxt = nxt >= STAGES ? nxt - STAGES : nxt;
-    compute(cur, nxt);
+    if (!abl_mfma) compute(cur, nxt);
+    else {
+#pragma unroll
+      for (int q = 0; q < LOADS; ++q) issue_piece(nxt, q);
+    }
     // tile kt+1 must have landed; the AHEAD-1 younger tiles stay in flight
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!abl_bar) __builtin_amdgcn_s_barrier();
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tiles
@@ -723,6 +760,17 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * g.acc_scale;
 
+  if (MILAN_ABLATE_BUILD && (g.debug & 8)) {  // main loop only
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 123.456f) g.C[0] = t;
+    return;
+  }
   run_epilogue<TM, TN>(g, acc, smem, wave, lane, tile_m * BM + wm * 128,
                        tile_n * BN + wn * 64);
 }
@@ -897,12 +945,17 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   }
   MILAN_REQUIRE(g.A2 == nullptr || (g.a_split && g.N > 64 && g.M >= 256 &&
                                     g.KH == 1 && g.KW == 1 && g.K1 % 16 == 0 &&
-                                    g.tile_hint == 0),
+                                    (g.tile_hint == 0 || g.tile_hint >= 3)),
                 MILAN_ERR_SHAPE, "gemm: two-source A needs the split16 kernels");
   if (g.a_split) {
-    MILAN_REQUIRE(cin32, MILAN_ERR_SHAPE,
-                  "gemm: split-f16 operands need Cin %% 32 == 0 (Cin=%d)", g.Cin);
     if (g.acc_scale == 0.f) g.acc_scale = 1.f;
+    if (!cin32) {
+      // per-lane taps (8-slot groups): only the narrow-N tile is built for it
+      MILAN_REQUIRE(g.Cin % 8 == 0 && g.N <= 64 && !g.A2, MILAN_ERR_SHAPE,
+                    "gemm: split-f16 operands with Cin %% 32 != 0 need "
+                    "Cin %% 8 == 0 and N <= 64 (Cin=%d N=%d)", g.Cin, g.N);
+      return launch_cfg<256, 64, 2, false, true>(g, s);
+    }
     if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
     // Measured on the 4096-neuron workload (profiles/): the 4-wave 256x128
     // tile with 16-slot k-tiles, a 3-deep ring and DMA pieces interleaved with
@@ -910,6 +963,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     // configuration for every N > 64 layer; the others stay reachable through
     // tile_hint for experiments.
     if (g.tile_hint == 3) return launch_split16<256, 256, 4>(g, s);
+    if (g.tile_hint == 4 && g.M >= 256) return launch_split16<256, 128, 3>(g, s);
     if (g.tile_hint == 1) return launch_cfg<256, 128, 3, true, true>(g, s);
     if (g.tile_hint == 2) return launch_cfg<128, 128, 2, true, true>(g, s);
     if (g.M >= 256 && g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);

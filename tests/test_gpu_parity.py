@@ -429,6 +429,37 @@ def test_split_f16_encoder_matches_reference_golden(dev, goldens, golden_meta,
     ctx.close()
 
 
+@pytest.mark.parametrize('hw', [(96, 96), (75, 101), (64, 33)])
+def test_split_f16_pixel_pair_stem(dev, hw):
+    """Split mode runs the 7x7/2 stem as a KH=7 x KW=4 conv over pixel-pair
+    groups (encoder.hip).  Odd widths exercise the trailing half-empty group
+    and the right-hand padding; the raw conv1 tap (first `width` feature
+    columns, nethook's pre-BN 'conv1') must agree with the fp32 path to
+    fp32-class error, and u8 / float inputs must give identical bits."""
+    h, w = hw
+    width, k = 16, 3
+    blocks = synthetic.RESNET_BLOCKS['resnet50']
+    sd = synthetic.resnet_state_dict('resnet50', seed=5, width=width,
+                                     prefix='encoder.encoder.model.')
+    ctx = hip.Context(hip.make_dims(sd, 10, blocks=blocks), sd, dev)
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    images = torch.randint(0, 256, (k, 3, h, w), dtype=torch.uint8, generator=g)
+    masks = (torch.rand(k, 1, h, w, generator=g) > 0.6).to(torch.uint8)
+    want = O.encode(O.byte_to_float(images)[None], masks[None].float(), sd,
+                    blocks=blocks)[0]
+    f32 = ctx.encode(images, masks).cpu()
+    ctx.set_precision('split_f16')
+    sp_u8 = ctx.encode(images, masks).cpu()
+    sp_f = ctx.encode(O.byte_to_float(images), masks.float()).cpu()
+    assert torch.equal(sp_u8, sp_f)
+    close(sp_u8, want, rtol=2e-3, atol=2e-4)
+    tap0 = slice(0, width)
+    scale = float(want[:, tap0].abs().max())
+    assert float((sp_u8[:, tap0] - f32[:, tap0]).abs().max()) < 2e-6 * max(scale, 1.0)
+    close(sp_u8[:, tap0], want[:, tap0], rtol=1e-4, atol=1e-5)
+    ctx.close()
+
+
 def test_split_f16_describe_end_to_end(dev):
     nv, width, k, n, size = 60, 32, 5, 6, 96
     blocks = synthetic.RESNET_BLOCKS['resnet50']
