@@ -44,8 +44,9 @@ enum {
 
 enum { MILAN_DTYPE_U8 = 0, MILAN_DTYPE_F32 = 1 };
 
-/* src/milan/decoders.py:217-221 */
-enum { MILAN_GREEDY = 0, MILAN_BEAM = 2, MILAN_RERANK = 3 };
+/* src/milan/decoders.py:217-221; MILAN_FORCED = `strategy=<tensor>` (teacher
+ * forcing, decoders.py:444-445). */
+enum { MILAN_GREEDY = 0, MILAN_FORCED = 1, MILAN_BEAM = 2, MILAN_RERANK = 3 };
 
 typedef struct milan_ctx milan_ctx;
 typedef void* milan_stream; /* hipStream_t */
@@ -128,6 +129,11 @@ int milan_step(milan_ctx* ctx, const float* features, int rows, int k,
  *   strategy MILAN_GREEDY: tokens (n,length), scores (n); predictions
  *     (n,length,V) and attentions (n,length,k) optional (may be NULL);
  *     beam_* must be NULL.  mi = use the LM per step (decoders.py:624-630).
+ *   strategy MILAN_FORCED: as MILAN_GREEDY but the token fed to step t+1 is
+ *     tokens[:, t] -- `tokens` (n,length) is an INPUT holding the forced ids
+ *     (0 <= id < V, validated by the caller) and is left unchanged, scores
+ *     accumulate predictions[b, t, tokens[b, t]] (what Decoder.score sums,
+ *     decoders.py:636-711); predictions is required.
  *   strategy MILAN_BEAM / MILAN_RERANK: allennlp-2.10 BeamSearch semantics
  *     (decoders.py:467-484) then best-of-beam / LM rerank (decoders.py:492-512).
  *     beam_tokens (n,beam,length) int64, beam_scores (n,beam),

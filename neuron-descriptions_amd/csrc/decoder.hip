@@ -743,6 +743,26 @@ __global__ void greedy_record_kernel(const float* __restrict__ cand_v,
       attentions[((long)r * T + t) * k + j] = att[(long)r * k + j];
 }
 
+// strategy=<tensor>: the forced token is the next input, its log-prob the score
+__global__ void forced_record_kernel(const float* __restrict__ pred,
+                                     long pred_stride, int V,
+                                     const float* __restrict__ att, int n, int k,
+                                     int t, int T,
+                                     const int64_t* __restrict__ tokens,
+                                     float* __restrict__ scores,
+                                     float* __restrict__ attentions,
+                                     int64_t* __restrict__ next_tok) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int64_t tok = tokens[(long)r * T + t];
+  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);  // callers validate the range
+  next_tok[r] = tok;
+  scores[r] = (t == 0 ? 0.f : scores[r]) + pred[(long)r * pred_stride + tok];
+  if (attentions)
+    for (int j = 0; j < k; ++j)
+      attentions[((long)r * T + t) * k + j] = att[(long)r * k + j];
+}
+
 __global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1144,16 +1164,19 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   MILAN_TRY(check_dims(c, k));
   const milan_dims& d = c->d;
   const int H = d.hidden_size, V = d.vocab_size;
-  MILAN_REQUIRE(strategy == MILAN_GREEDY || strategy == MILAN_BEAM ||
-                    strategy == MILAN_RERANK,
+  MILAN_REQUIRE(strategy == MILAN_GREEDY || strategy == MILAN_FORCED ||
+                    strategy == MILAN_BEAM || strategy == MILAN_RERANK,
                 MILAN_ERR_ARG, "unknown strategy: %d", strategy);
   MILAN_REQUIRE(!(mi && strategy == MILAN_RERANK), MILAN_ERR_ARG,
                 "cannot set `mi=` decoding when reranking");
   MILAN_REQUIRE(!(mi || strategy == MILAN_RERANK) || d.has_lm, MILAN_ERR_NO_LM,
                 "cannot use MI/rerank decoding without an LM");
   MILAN_REQUIRE(n > 0 && length > 0, MILAN_ERR_SHAPE, "decode: empty batch");
-  const bool greedy = strategy == MILAN_GREEDY;
+  const bool forced = strategy == MILAN_FORCED;
+  const bool greedy = strategy == MILAN_GREEDY || forced;
   if (greedy) beam = 1;
+  MILAN_REQUIRE(!forced || predictions, MILAN_ERR_ARG,
+                "teacher forcing needs the predictions output");
   MILAN_REQUIRE(beam >= 1 && beam <= V, MILAN_ERR_ARG,
                 "beam_size %d must be in 1..vocab_size", beam);
   MILAN_REQUIRE(greedy || (beam_tokens && beam_scores), MILAN_ERR_ARG,
@@ -1197,9 +1220,14 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
           b.logits, lm_logits, temperature, n, V, 1, nullptr, 0, b.cand_v,
           b.cand_i, predictions ? predictions + (long)t * V : nullptr,
           (long)length * V, s));
-      hipLaunchKernelGGL(greedy_record_kernel, dim3(nblk(n)), dim3(256), 0, s,
-                         b.cand_v, b.cand_i, b.att, n, k, t, length, tokens,
-                         scores, attentions, b.tok);
+      if (forced)
+        hipLaunchKernelGGL(forced_record_kernel, dim3(nblk(n)), dim3(256), 0, s,
+                           predictions + (long)t * V, (long)length * V, V, b.att,
+                           n, k, t, length, tokens, scores, attentions, b.tok);
+      else
+        hipLaunchKernelGGL(greedy_record_kernel, dim3(nblk(n)), dim3(256), 0, s,
+                           b.cand_v, b.cand_i, b.att, n, k, t, length, tokens,
+                           scores, attentions, b.tok);
       float* tmp = h; h = hn; hn = tmp;
       tmp = cc; cc = cn; cn = tmp;
     }

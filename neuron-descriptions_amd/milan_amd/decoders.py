@@ -257,10 +257,13 @@ class Decoder(nn.Module):
             if strategy.shape[-1] != length:
                 raise ValueError(f'strategy must have length {length}, '
                                  f'got {strategy.shape[-1]}')
-            raise NotImplementedError(
-                'teacher forcing (strategy=<tensor>) belongs to training / '
-                'Decoder.score and is outside the MI355X inference path')
-        if strategy == STRATEGY_SAMPLE:
+            if strategy.shape[0] != batch_size:
+                raise ValueError('strategy must have one row per sample, got '
+                                 f'{strategy.shape[0]} for batch {batch_size}')
+            if strategy.numel() and (int(strategy.min()) < 0 or
+                                     int(strategy.max()) >= self.vocab_size):
+                raise IndexError('index out of range in self')  # nn.Embedding
+        if isinstance(strategy, str) and strategy == STRATEGY_SAMPLE:
             raise NotImplementedError(
                 "strategy='sample' is outside the MI355X inference path")
         if self.training:
@@ -269,8 +272,12 @@ class Decoder(nn.Module):
                 '.eval() -- milan.pretrained() returns eval-mode models')
 
         ctx = self._context()
-        hip_strategy = _HIP_STRATEGY[strategy]
-        full = hip_strategy == hip.GREEDY
+        forced = None
+        if isinstance(strategy, torch.Tensor):  # teacher forcing (:444-445)
+            hip_strategy, forced = hip.FORCED, strategy
+        else:
+            hip_strategy = _HIP_STRATEGY[strategy]
+        full = hip_strategy in (hip.GREEDY, hip.FORCED)
         gs = group_size or 0
         if encode and self._has_hip_encoder():
             images = images_or_features
@@ -278,18 +285,20 @@ class Decoder(nn.Module):
                 images = images.unsqueeze(1)
                 masks = None if masks is None else masks.unsqueeze(1)
             out = ctx.describe(images, masks, hip_strategy, length, beam_size,
-                               mi, temperature, group_size=gs, want_full=full)
+                               mi, temperature, group_size=gs, want_full=full,
+                               forced=forced)
         else:
             if encode:
                 features = self.encode(images_or_features, masks=masks)
             else:
                 features = images_or_features
             out = ctx.decode(features, hip_strategy, length, beam_size, mi,
-                             temperature, group_size=gs, want_full=full)
+                             temperature, group_size=gs, want_full=full,
+                             forced=forced)
 
         tokens, scores = out['tokens'], out['scores']
         beam_captions = beam_scores = beam_tokens = None
-        if hip_strategy != hip.GREEDY:
+        if not full:
             # allennlp returns T' <= length columns; with several groups the
             # tensors keep the longest group's T' (shorter groups are padded
             # with <stop>, which reconstruct() ignores).
@@ -353,6 +362,57 @@ class Decoder(nn.Module):
                            state=DecoderState(h=h2, c=c2, h_lm=h_lm, c_lm=c_lm))
 
     # -- dataset driver ---------------------------------------------------------------
+    def score(self,
+              captions,
+              images_or_features: torch.Tensor,
+              masks: Optional[torch.Tensor] = None,
+              device=None,
+              **kwargs: Any) -> torch.Tensor:
+        """Force decode the captions, returning their total scores
+        (reference :636-711): log-probabilities (`mi=False`) or mutual
+        informations (`mi=True`).
+
+        `captions` are strings (needs `indexer.tokenize`, i.e. the spaCy
+        tokenizer the checkpoint was trained with, or any callable) or --
+        extension -- already tokenized sequences of token strings, which are
+        indexed with `Indexer.index` directly.
+        """
+        for forbidden in ('strategy', 'length'):
+            if forbidden in kwargs:
+                raise ValueError(f'option disallowed: {forbidden}')
+        if masks is not None and len(masks) != len(images_or_features):
+            raise ValueError('images_or_features and masks must have the '
+                             f'same batch size; got {len(images_or_features)} '
+                             f'and {len(masks)}')
+        if len(images_or_features) == 1:
+            images_or_features = images_or_features.expand(
+                len(captions), *images_or_features.shape[1:])
+            if masks is not None:
+                masks = masks.expand(len(captions), *masks.shape[1:])
+        elif len(images_or_features) != len(captions):
+            raise ValueError('images_or_features must have batch size 1 or '
+                             f'{len(captions)}; got {len(images_or_features)}')
+        if device is not None:
+            self.to(device)
+        pretokenized = len(captions) > 0 and not isinstance(captions[0], str)
+        index = self.indexer.index if pretokenized else self.indexer
+        targets = torch.tensor(index(captions))[:, 1:]
+        _, length = targets.shape
+        outputs = self(images_or_features, masks=masks, strategy=targets,
+                       length=length, **kwargs)
+        indexed = index(captions, start=False, stop=True, pad=False, unk=True)
+        # total_i = sum_t predictions[i, t, indexed_i[t]] over the caption's own
+        # length (the reference's per-caption Python gather, one device gather)
+        lens = torch.tensor([len(ix) for ix in indexed])
+        padded = torch.zeros(len(indexed), length, dtype=torch.long)
+        for i, ix in enumerate(indexed):
+            padded[i, :len(ix)] = torch.tensor(ix, dtype=torch.long)
+        pred = outputs.predictions
+        picked = pred.gather(2, padded.to(pred.device).unsqueeze(-1)).squeeze(-1)
+        keep = torch.arange(length)[None, :] < lens[:, None]
+        totals = (picked * keep.to(pred.device, pred.dtype)).sum(dim=1)
+        return totals if device is None else totals.to(device)
+
     def predict(self,
                 dataset: data.Dataset,
                 mask: bool = True,

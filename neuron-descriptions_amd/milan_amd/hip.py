@@ -17,7 +17,7 @@ import torch
 
 LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so'
 
-GREEDY, BEAM, RERANK = 0, 2, 3  # MILAN_GREEDY / MILAN_BEAM / MILAN_RERANK
+GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _RERANK
 PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
 PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16}
 DTYPE_U8, DTYPE_F32 = 0, 1
@@ -327,16 +327,26 @@ class Context:
                                     _stream(self.device)))
         return pred, att, h2, c2, h_lm, c_lm
 
-    def _alloc_outputs(self, n, k, strategy, length, beam, want_full):
+    def _alloc_outputs(self, n, k, strategy, length, beam, want_full,
+                       forced=None):
         dev = self.device
-        out = dict(tokens=torch.empty(n, length, dtype=torch.long, device=dev),
+        if strategy == FORCED:
+            # teacher forcing: `tokens` is the INPUT of milan_decode
+            if forced is None or tuple(forced.shape) != (n, length):
+                raise ValueError('FORCED decoding needs forced tokens of shape '
+                                 f'({n}, {length})')
+            tokens = forced.to(device=dev, dtype=torch.long).contiguous().clone()
+            want_full = True
+        else:
+            tokens = torch.empty(n, length, dtype=torch.long, device=dev)
+        out = dict(tokens=tokens,
                    scores=torch.empty(n, device=dev),
                    predictions=None,
                    attentions=None,
                    beam_tokens=None,
                    beam_scores=None,
                    out_len=None)
-        if strategy == GREEDY:
+        if strategy in (GREEDY, FORCED):
             if want_full:
                 out['predictions'] = torch.empty(n,
                                                  length,
@@ -360,13 +370,15 @@ class Context:
                mi: bool,
                temperature: float,
                group_size: int = 0,
-               want_full: bool = True):
+               want_full: bool = True,
+               forced: Optional[torch.Tensor] = None):
         n, k, _ = features.shape
         features = _dev(features, self.device, torch.float32)
-        if getattr(self, '_graphs', False):
+        if getattr(self, '_graphs', False) and strategy != FORCED:
             return self._decode_graphed(features, strategy, length, beam, mi,
                                         temperature, group_size, want_full)
-        out = self._alloc_outputs(n, k, strategy, length, beam, want_full)
+        out = self._alloc_outputs(n, k, strategy, length, beam, want_full,
+                                  forced)
         groups = (n + group_size - 1) // group_size if group_size > 0 else 1
         out['out_len'] = torch.full((groups,),
                                     length,
@@ -444,7 +456,8 @@ class Context:
                  temperature: float,
                  group_size: int = 0,
                  want_full: bool = False,
-                 want_features: bool = False):
+                 want_features: bool = False,
+                 forced: Optional[torch.Tensor] = None):
         """Fused hot path on (n,k,3,H,W) images (+ (n,k,1,H,W) masks)."""
         n, k, ch, h, w = images.shape
         idt = DTYPE_U8 if images.dtype == torch.uint8 else DTYPE_F32
@@ -455,7 +468,8 @@ class Context:
             mdt = DTYPE_U8 if masks.dtype == torch.uint8 else DTYPE_F32
             masks = _dev(masks, self.device,
                          None if mdt == DTYPE_U8 else torch.float32)
-        out = self._alloc_outputs(n, k, strategy, length, beam, want_full)
+        out = self._alloc_outputs(n, k, strategy, length, beam, want_full,
+                                  forced)
         groups = (n + group_size - 1) // group_size if group_size > 0 else 1
         out['out_len'] = torch.full((groups,),
                                     length,

@@ -115,11 +115,57 @@ class Indexer:
             return self.tokens[token]
         return self.ids[token]
 
-    def __call__(self, *args, **kwargs):
-        raise NotImplementedError(
-            'text -> ids indexing needs the spaCy tokenizer and is only used '
-            'by training / Decoder.score in the reference; it is outside the '
-            'inference hot path this build covers')
+    # -- tokens -> ids (reference lang.py:331-514) ------------------------------
+    def __call__(self, texts, **kwargs):
+        """Tokenize then index.  `tokenize` is the spaCy-backed `Tokenizer` in
+        the reference; any callable str|[str] -> tokens|[tokens] works here."""
+        if not callable(self.tokenize):
+            raise NotImplementedError(
+                'text -> ids indexing needs a tokenizer: the checkpoint\'s spaCy '
+                'tokenizer is not available in this build; set '
+                '`indexer.tokenize` to a callable or pass pre-tokenized '
+                'sequences to `Indexer.index`')
+        return self.index(self.tokenize(texts), **kwargs)
+
+    def index(self,
+              tokenized,
+              start: Optional[bool] = None,
+              stop: Optional[bool] = None,
+              pad: Optional[bool] = None,
+              unk: Optional[bool] = None,
+              length: Optional[int] = None):
+        """Map token strings to ids; one sequence or a batch of sequences.
+
+        `length` does not count the start/stop tokens; sequences are truncated
+        (keeping room for `<stop>`) and, with `pad`, padded to it.  Unknown
+        tokens become `<unk>` when `unk`, otherwise they are dropped.
+        """
+        if not tokenized:
+            return ()
+        singleton = isinstance(tokenized[0], str)
+        start = self.start if start is None else start
+        stop = self.stop if stop is None else stop
+        pad = self.pad if pad is None else pad
+        unk = self.unk if unk is None else unk
+        batch = [tokenized] if singleton else tokenized
+        length = length or self.length or max(len(toks) for toks in tokenized)
+        length += int(bool(start)) + int(bool(stop))
+        ids = self.vocab.ids
+        indexed = []
+        for tokens in batch:
+            row = [self.start_index] if start else []
+            if unk:
+                row += [ids.get(tok, self.unk_index) for tok in tokens]
+            else:
+                row += [ids[tok] for tok in tokens if tok in ids]
+            if stop:
+                del row[max(length - 1, 0):]
+                row.append(self.stop_index)
+            if len(row) < length and pad:
+                row += [self.pad_index] * (length - len(row))
+            del row[length:]
+            indexed.append(tuple(row))
+        return indexed[0] if singleton else tuple(indexed)
 
     # -- ids -> tokens ------------------------------------------------------
     def unindex(self,

@@ -29,3 +29,15 @@ def goldens():
 def golden_meta():
     with open(GOLDEN_DIR / 'reference_goldens.json') as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def forced_goldens():
+    """Teacher-forcing / Decoder.score goldens (make_golden_forced.py)."""
+    return torch.load(GOLDEN_DIR / 'reference_goldens_forced.pt')
+
+
+@pytest.fixture(scope='session')
+def forced_meta():
+    with open(GOLDEN_DIR / 'reference_goldens_forced.json') as f:
+        return json.load(f)
