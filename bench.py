@@ -224,6 +224,15 @@ def main():
         return
     neurons = args.steps * args.chunk * world
     value = neurons / elapsed
+    # host-side caption reconstruction of the gathered top-1 tokens (section 8d:
+    # timed and reported separately from `value`)
+    from milan_amd import lang
+    indexer = lang.Indexer(lang.Vocab(synthetic.vocab_tokens(nv)), None, True,
+                           True, True, True, args.length)
+    t3 = time.perf_counter()
+    captions = indexer.reconstruct(all_tokens.cpu().tolist())
+    reconstruct_ms = 1e3 * (time.perf_counter() - t3)
+    assert len(captions) == all_tokens.shape[0]
     result = {
         'metric': 'neuron-descriptions/sec (whole node), 4096 neurons x k=15 '
                   'exemplars',
@@ -251,7 +260,20 @@ def main():
             'parallelism': f'neuron-sharded x{world}',
             'gathered_tokens': list(all_tokens.shape),
         },
+        'host_reconstruct_ms': reconstruct_ms,
     }
+    # HBM bytes per launch of the dominant kernel: PMC counters need their own
+    # rocprofv3 passes (scratch/pmc_traffic.sh), so the figure is read from the
+    # committed summary of those passes, not collected live.
+    traffic_bytes, traffic_note = None, 'not collected (PMC needs separate rocprofv3 passes)'
+    tpath = pathlib.Path(__file__).resolve().parent / 'profiles' / 'r1_hbm_traffic.json'
+    if args.precision != 'f32' and tpath.exists():
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic_bytes = tj['traffic_gb_per_launch'] * 1e9
+        traffic_note = (f"bytes per launch of {tj['dominant_kernel']} "
+                        f"(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), offline "
+                        f"rocprofv3 --pmc passes summarised in profiles/{tpath.name}")
     if gemm_ms:
         g_alg = algorithmic_gflop(beam, strategy == hip.RERANK)
         per_launch_flop = g_alg * 1e9 * args.steps * args.chunk / gemm_launches
@@ -271,7 +293,8 @@ def main():
             # the matrix cores execute 3 f16 MFMA flops per algorithmic flop
             'mfma_issue_frac': (3 * achieved / peak) if split else
             achieved / peak,
-            'traffic': None,
+            'traffic': traffic_bytes,
+            'traffic_note': traffic_note,
             'launches': gemm_launches,
             'avg_launch_ms': avg_ms,
             'algorithmic_gflop_per_neuron': g_alg,
