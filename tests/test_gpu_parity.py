@@ -253,7 +253,8 @@ def _check_beams(out, want_tokens, want_scores, length_used):
 
 
 @pytest.mark.parametrize('size,beam,length', [('small', 5, 8), ('small', 3, 15),
-                                              ('full', 16, 15)])
+                                              ('full', 16, 15),
+                                              ('full', 50, 15)])
 def test_beam_search_and_rerank_match_oracle(dev, golden_meta, size, beam,
                                              length):
     ctx, sd, feats, nv = _dec(golden_meta[f'dec_{size}'], dev)

@@ -1,0 +1,133 @@
+"""Size-independent properties of the hot path at BASELINE's real shapes
+(ResNet-101 trunk, 224x224, k=15, F=3904, V=5004, beam 50 + rerank) where the
+CPU oracle would take minutes: determinism, neuron-permutation equivariance,
+chunk invariance, and the beam-search invariants checked THROUGH the C ABI
+(every beam score is the teacher-forced log-prob of its tokens; beams sorted;
+the rerank choice is argmax(beam_score - lambda * lm_score))."""
+import pytest
+import torch
+
+from milan_amd import hip, synthetic
+
+pytestmark = pytest.mark.gpu
+
+NV, K, SIZE, BEAM, LENGTH, LAMBDA = 5000, 15, 224, 50, 15, 0.2
+N = 24  # neurons (360 images): a partial last M-tile in every conv
+
+
+@pytest.fixture(scope='module')
+def world():
+    dev = hip.require_device('cuda')
+    sd = synthetic.milan_state_dict(NV + 4, seed=0)
+    ctx = hip.Context(hip.make_dims(sd, NV), sd, dev)
+    ctx.set_precision('split_f16')  # the bench's mode
+    images, masks = synthetic.exemplars(N, k=K, size=SIZE, seed=1,
+                                        zero_every=97)
+    out = ctx.describe(images, masks, hip.RERANK, LENGTH, BEAM, False, LAMBDA,
+                       want_features=True)
+    yield ctx, images, masks, out
+    ctx.close()
+
+
+def test_rerun_is_bit_identical(world):
+    ctx, images, masks, out = world
+    again = ctx.describe(images, masks, hip.RERANK, LENGTH, BEAM, False,
+                         LAMBDA, want_features=True)
+    for key in ('features', 'tokens', 'scores', 'beam_tokens', 'beam_scores'):
+        assert torch.equal(out[key], again[key]), key
+
+
+def test_neuron_permutation_equivariance(world):
+    """No cross-neuron coupling anywhere: shuffling the
+    neurons shuffles the results.  group_size=1 removes allennlp's
+    batch-level early exit, the only batch-dependent step."""
+    ctx, images, masks, _ = world
+    base = ctx.describe(images, masks, hip.RERANK, LENGTH, BEAM, False, LAMBDA,
+                        group_size=1, want_features=True)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(3))
+    shuf = ctx.describe(images[perm], masks[perm], hip.RERANK, LENGTH, BEAM,
+                        False, LAMBDA, group_size=1, want_features=True)
+    dperm = perm.to(base['tokens'].device)
+    assert torch.equal(shuf['features'], base['features'][dperm])
+    assert torch.equal(shuf['beam_tokens'], base['beam_tokens'][dperm])
+    assert torch.equal(shuf['tokens'], base['tokens'][dperm])
+    assert torch.equal(shuf['scores'], base['scores'][dperm])
+    assert torch.equal(shuf['out_len'], base['out_len'][dperm])
+
+
+def test_chunk_invariance(world):
+    """One launch over N neurons == launches over sub-chunks (what
+    `predict(chunk_size=...)` relies on)."""
+    ctx, images, masks, _ = world
+    whole = ctx.describe(images, masks, hip.RERANK, LENGTH, BEAM, False,
+                         LAMBDA, group_size=8)
+    parts = [ctx.describe(images[lo:lo + 8], masks[lo:lo + 8], hip.RERANK,
+                          LENGTH, BEAM, False, LAMBDA, group_size=8)
+             for lo in range(0, N, 8)]
+    cat = {key: torch.cat([p[key] for p in parts]) for key in whole
+           if isinstance(whole[key], torch.Tensor)}
+    assert torch.equal(whole['out_len'], cat['out_len'])
+    # The launcher picks tile shapes by row count (8 vs 24 neurons), so the
+    # fp32 accumulation grouping -- not the arithmetic -- differs in the last
+    # bits: sorted beam scores stay close, beams may swap at exact near-ties.
+    torch.testing.assert_close(whole['beam_scores'], cat['beam_scores'],
+                               rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(whole['scores'], cat['scores'], rtol=1e-5,
+                               atol=1e-3)
+    same_top1 = (whole['tokens'] == cat['tokens']).all(dim=1)
+    assert same_top1.float().mean() >= 0.9
+    same_beams = (whole['beam_tokens'] == cat['beam_tokens']).all(dim=2)
+    assert same_beams.float().mean() >= 0.9
+
+
+def test_zero_mask_rows_and_feature_sanity(world):
+    ctx, images, masks, out = world
+    feats = out['features'].cpu()
+    flat_masks = masks.reshape(N * K, -1)
+    zero = flat_masks.sum(1) == 0
+    assert zero.any(), 'workload should contain all-zero masks'
+    assert feats.reshape(N * K, -1)[zero].eq(0).all()
+    assert not torch.isnan(feats).any() and feats.abs().max() < 1e4
+    # post-ReLU taps pooled with non-negative weights are non-negative; only
+    # the raw conv1 tap (first 64 columns) can be negative
+    assert feats[..., 64:].min() >= 0
+
+
+def test_beam_scores_are_sorted_and_teacher_forced_log_probs(world):
+    ctx, images, masks, out = world
+    bs = out['beam_scores']
+    assert (bs[:, :-1] >= bs[:, 1:]).all(), 'beams must be sorted descending'
+    stop = NV + 1
+    bt = out['beam_tokens']                       # (N, BEAM, LENGTH)
+    feats = out['features']
+    # force-decode every beam through the same kernels
+    rows = bt.reshape(N * BEAM, LENGTH)
+    f_rows = feats.repeat_interleave(BEAM, dim=0)
+    forced = ctx.decode(f_rows, hip.FORCED, LENGTH, 1, False, LAMBDA,
+                        forced=rows)
+    lp = forced['predictions'].gather(2, rows.unsqueeze(-1)).squeeze(-1)
+    # allennlp stops accumulating after the first <stop>
+    ended = (rows == stop).cumsum(1)
+    keep = (ended == 0) | ((ended == 1) & (rows == stop))
+    want = (lp * keep).sum(1).reshape(N, BEAM)
+    torch.testing.assert_close(bs, want, rtol=1e-4, atol=5e-3)
+
+
+def test_rerank_choice_is_argmax_of_pmi(world):
+    ctx, images, masks, out = world
+    stop, start = NV + 1, NV
+    tp = int(out['out_len'].max())
+    bt = out['beam_tokens'][:, :, :tp]
+    seqs = torch.cat([torch.full((N * BEAM, 1), start, dtype=torch.long,
+                                 device=bt.device),
+                      bt.reshape(N * BEAM, tp)], dim=1)
+    lm = ctx.lm_score(seqs).reshape(N, BEAM)
+    pmi = out['beam_scores'] - LAMBDA * lm
+    best = pmi.max(1)
+    torch.testing.assert_close(out['scores'], best.values, rtol=1e-5,
+                               atol=1e-4)
+    chosen = bt[torch.arange(N), best.indices]
+    top2 = pmi.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3  # skip numerical near-ties
+    assert torch.equal(out['tokens'][:, :tp][clear], chosen[clear])
+    assert clear.float().mean() > 0.5
