@@ -103,9 +103,9 @@ def main():
                     help='do not bracket GEMM launches with HIP events')
     ap.add_argument('--pipeline', type=int, default=0,
                     help='1: run the encoder of step i+1 on a second HIP stream '
-                    'while step i decodes (measured 2x SLOWER on MI355X: the '
-                    'decode loop\'s ~450 dependent launches each queue behind a '
-                    'full-chip conv grid); 0: strictly serial steps (default)')
+                    'while step i decodes (measured +2 % with --no-profile, 2x '
+                    'slower with per-launch event profiling on); 0: strictly '
+                    'serial steps (default)')
     ap.add_argument('--from-host-steps', type=int, default=0,
                     help='also time this many steps fed from pinned host uint8 '
                     'tensors through the double-buffered ingest (PCIe-inclusive '
@@ -121,7 +121,9 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = sharding.init_from_env(args.gpus)
-    device = torch.device('cuda', local)
+    # one GPU per rank; `% device_count` only matters for the debug set-up of
+    # several gloo ranks sharing the single GPU of a test box
+    device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
 
     nv = args.vocab

@@ -513,15 +513,17 @@ class Context:
         ~450 small, latency-bound launches.  On
         separate streams (milan_encode / milan_decode take the stream and the
         workspace from the caller) the decode kernels could fill the gaps of
-        the encoder grid.  MEASURED (round 1): 461 vs 920 neurons/s -- every one
-        of the dependent decode launches queues behind a full-chip convolution
-        grid, so the serial order wins; kept for experiments
+        the encoder grid.  MEASURED (round 1): 1021 vs 1005 neurons/s serial
+        (+2 %; two fully independent contexts on two streams: +3.5 %) -- the
+        convolution grids already fill every CU, so only the decode loop's own
+        latency gaps are recovered; with per-launch event profiling on, the
+        pipelined order is 2x SLOWER.  Kept for experiments
         (bench.py --pipeline 1), not used by predict().
         """
         dev = self.device
         cur = torch.cuda.current_stream(dev)
         enc_s = torch.cuda.Stream(device=dev)
-        dec_s = torch.cuda.Stream(device=dev)
+        dec_s = torch.cuda.Stream(device=dev)  # (high-priority decode: -11 %)
         feats = [None, None]
         feats_free = [None, None]
         ws = {}

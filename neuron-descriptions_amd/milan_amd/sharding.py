@@ -52,11 +52,21 @@ def init_from_env(expected_world: Optional[int] = None,
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # MILAN_DIST_BACKEND=gloo: collectives staged through host memory
+            # (CPU tests; several ranks sharing one GPU on a 1-GPU box)
+            backend = os.environ.get('MILAN_DIST_BACKEND') or (
+                'nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _comm_device(device: torch.device) -> torch.device:
+    """Where collective buffers live: the GPU for RCCL, host memory for gloo."""
+    if is_distributed() and dist.get_backend() == 'gloo':
+        return torch.device('cpu')
+    return torch.device(device)
 
 
 def barrier() -> None:
@@ -73,7 +83,7 @@ def finalize() -> None:
 def max_over_ranks(value: float, device: torch.device) -> float:
     if not is_distributed():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -108,15 +118,16 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]],
             continue
         dtype = torch.float32 if is_float else torch.int64
         total = sum(int(torch.Size(s).numel()) for _, s, _ in names)
-        flat = torch.empty(total, dtype=dtype, device=device)
+        flat = torch.empty(total, dtype=dtype, device=_comm_device(device))
         if rank == src:
             off = 0
             for k, s, _ in names:
                 n = int(torch.Size(s).numel())
-                flat[off:off + n] = sd[k].reshape(-1).to(device=device,
+                flat[off:off + n] = sd[k].reshape(-1).to(device=flat.device,
                                                          dtype=dtype)
                 off += n
         dist.broadcast(flat, src=src)
+        flat = flat.to(device)
         off = 0
         for k, s, d in names:
             n = int(torch.Size(s).numel())
@@ -134,6 +145,9 @@ def gather_results(tokens: torch.Tensor,
     if not is_distributed():
         return tokens, scores
     world, rank = dist.get_world_size(), dist.get_rank()
+    out_device = tokens.device
+    tokens = tokens.to(_comm_device(out_device))
+    scores = scores.to(_comm_device(out_device))
     n = torch.tensor([tokens.shape[0]], dtype=torch.int64, device=tokens.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -149,11 +163,13 @@ def gather_results(tokens: torch.Tensor,
         bufs_s = [torch.empty_like(pad_s) for _ in range(world)]
         dist.gather(pad_t, bufs_t, dst=dst)
         dist.gather(pad_s, bufs_s, dst=dst)
-        return (torch.cat([b[:c] for b, c in zip(bufs_t, counts_i)]),
-                torch.cat([b[:c] for b, c in zip(bufs_s, counts_i)]))
+        return (torch.cat([b[:c] for b, c in zip(bufs_t, counts_i)
+                           ]).to(out_device),
+                torch.cat([b[:c] for b, c in zip(bufs_s, counts_i)
+                           ]).to(out_device))
     dist.gather(pad_t, None, dst=dst)
     dist.gather(pad_s, None, dst=dst)
-    return tokens, scores
+    return tokens.to(out_device), scores.to(out_device)
 
 
 def shard_sequence(items: Sequence, world: int, rank: int) -> Sequence:
