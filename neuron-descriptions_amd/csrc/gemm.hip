@@ -120,8 +120,26 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
     const bool n_ok = n < g.N;  // N % 4 == 0 checked by the launcher
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+    // aux rows are fetched one row-tile ahead of the stores (see the split8
+    // epilogue below for why)
+    constexpr bool AUX = (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD ||
+                          EPI == EPI_BIAS_SIGMUL);
+    f32x4 res[AUX ? 2 : 1][8];
+    auto load_res = [&](int i, f32x4 (&r)[8]) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = row0 + i * 32 + it * 4 + (lane >> 4);
+        r[it] = (m < g.M && n_ok)
+                    ? *reinterpret_cast<const f32x4*>(g.aux + (long)m * g.ldaux + n)
+                    : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    if constexpr (AUX) load_res(0, res[0]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      if constexpr (AUX) {
+        if (i + 1 < TM) load_res(i + 1, res[(i + 1) & 1]);
+      }
       to_stage(i);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
@@ -130,10 +148,8 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
         f32x4 v = *reinterpret_cast<const f32x4*>(stage_out + row * SROW + col4);
         if (m < g.M && n_ok) {
           v += bias4;
-          if constexpr (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD ||
-                        EPI == EPI_BIAS_SIGMUL) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(
-                g.aux + (long)m * g.ldaux + n);
+          if constexpr (AUX) {
+            const f32x4 a = res[i & 1][it];
             if constexpr (EPI == EPI_BIAS_SIGMUL) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
