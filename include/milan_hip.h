@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MILAN_ABI_VERSION 1
+#define MILAN_ABI_VERSION 2
 
 enum {
   MILAN_OK = 0,
@@ -53,11 +53,18 @@ typedef void* milan_stream; /* hipStream_t */
 
 /* Model geometry.  Mirrors the constructor arguments of
  * src/milan/decoders.py:233-244, src/milan/lms.py:20-25 and the encoder
- * config of src/milan/encoders.py:326-351 (bottleneck ResNets only). */
+ * config of src/milan/encoders.py:326-351: all four pyramid configs --
+ * 'resnet50'/'resnet101' (bottleneck blocks), 'resnet18' (basic blocks) and
+ * 'alexnet'. */
+enum {
+  MILAN_TRUNK_BOTTLENECK = 0, /* taps conv1 + layer1..4, F = 61 * width      */
+  MILAN_TRUNK_BASIC = 1,      /* same taps, expansion 1,   F = 16 * width      */
+  MILAN_TRUNK_ALEXNET = 2     /* taps features.0/3/6/8/10, F = 18 * width      */
+};
 typedef struct milan_dims {
-  int32_t trunk_width;      /* 64 for torchvision resnet50/101/152          */
-  int32_t trunk_blocks[4];  /* {3,4,23,3} = resnet101                        */
-  int32_t feature_size;     /* 61 * trunk_width = 3904                       */
+  int32_t trunk_width;      /* 64 for the torchvision models                */
+  int32_t trunk_blocks[4];  /* {3,4,23,3} = resnet101 (unused for alexnet)   */
+  int32_t feature_size;     /* 61 / 16 / 18 * trunk_width by trunk_kind      */
   int32_t hidden_size;      /* 512                                           */
   int32_t embedding_size;   /* 128                                           */
   int32_t attention_size;   /* min(hidden, feature) = 512 (decoders.py:50)   */
@@ -69,6 +76,7 @@ typedef struct milan_dims {
   int32_t lm_hidden_size;   /* 512                                           */
   int32_t lm_embedding_size;/* 128                                           */
   int32_t lm_layers;        /* 2                                             */
+  int32_t trunk_kind;       /* MILAN_TRUNK_* (0 = bottleneck ResNet)         */
 } milan_dims;
 
 int milan_abi_version(void);

@@ -124,6 +124,7 @@ struct Bottleneck {
   ConvW c1, c2, c3, down;
   ConvW c3d;  // [c3 | downsample] concatenated along K (split mode fusion)
   bool has_down = false;
+  bool basic = false;  // torchvision BasicBlock: c1 3x3 (stride), c2 3x3, no c3
 };
 struct LinearW {
   float* w = nullptr;  // [N][Kp]
@@ -180,6 +181,7 @@ struct milan_ctx {
   // encoder
   milan::ConvW stem;
   milan::ConvW stem_pair;  // split-f16 stem over pixel-pair groups (encoder.hip)
+  milan::ConvW alex[5];    // 'alexnet' config: features.0/3/6/8/10
   float *bn1_scale = nullptr, *bn1_shift = nullptr;
   std::vector<milan::Bottleneck> blocks[4];
   float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};

@@ -66,7 +66,7 @@ static const Tensor* find(milan_ctx* c, const std::string& name) {
 
 static int pack_conv(milan_ctx* c, const std::string& conv,
                      const std::string& bn, int stride, int pad, ConvW* out,
-                     hipStream_t s) {
+                     hipStream_t s, bool split_without_bn = false) {
   const Tensor* w = find(c, conv + ".weight");
   MILAN_REQUIRE(w && w->shape.size() == 4, MILAN_ERR_STATE,
                 "missing conv weight %s.weight", conv.c_str());
@@ -99,7 +99,19 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
                      out->cout, (int)w->shape[1], out->cin, out->kh, out->kw,
                      out->Kp, g, b, m, v, out->w, out->bias);
   MILAN_CHECK_HIP(hipGetLastError());
-  if (g && out->cin % 32 == 0)  // folded convs of the bottleneck stages
+  if (!g) {
+    // a conv with its own bias and no BatchNorm (AlexNet)
+    if (const Tensor* tb = find(c, conv + ".bias")) {
+      MILAN_REQUIRE(tb->numel() == out->cout, MILAN_ERR_SHAPE,
+                    "%s.bias has %ld entries for %d channels", conv.c_str(),
+                    (long)tb->numel(), out->cout);
+      MILAN_TRY(dev_alloc(c, (void**)&out->bias, sizeof(float) * out->cout));
+      MILAN_CHECK_HIP(hipMemcpyAsync(out->bias, tb->dev,
+                                     sizeof(float) * out->cout,
+                                     hipMemcpyDeviceToDevice, s));
+    }
+  }
+  if ((g || split_without_bn) && out->cin % 32 == 0)  // split-f16 copy
     MILAN_TRY(make_split_weight(c, out->w, out->cout, out->Kp, &out->ws,
                                 &out->ws_inv, s));
   return 0;
@@ -197,6 +209,24 @@ static int pack_stem_pairs(milan_ctx* c, const Tensor* w, hipStream_t s) {
 
 int encoder_finalize(milan_ctx* c, hipStream_t s) {
   const std::string p = "encoder.encoder.model.";
+  const int kind = c->d.trunk_kind;
+  if (kind == MILAN_TRUNK_ALEXNET) {
+    if (!find(c, p + "features.0.weight")) return 0;  // decoder-only context
+    // torchvision AlexNet.features: conv indices, strides, paddings
+    static const int idx[5] = {0, 3, 6, 8, 10};
+    static const int stride[5] = {4, 1, 1, 1, 1}, pad[5] = {2, 2, 1, 1, 1};
+    static const int mult[5] = {1, 3, 6, 4, 4};
+    for (int i = 0; i < 5; ++i) {
+      MILAN_TRY(pack_conv(c, p + "features." + std::to_string(idx[i]), "",
+                          stride[i], pad[i], &c->alex[i], s, i > 0));
+      MILAN_REQUIRE(c->alex[i].cout == mult[i] * c->d.trunk_width &&
+                        c->alex[i].bias != nullptr,
+                    MILAN_ERR_SHAPE,
+                    "features.%d: %d channels, expected %d (with a bias)", idx[i],
+                    c->alex[i].cout, mult[i] * c->d.trunk_width);
+    }
+    c->stem = c->alex[0];  // "encoder weights present" marker
+  } else {
   if (!find(c, p + "conv1.weight")) return 0;  // decoder-only context
   MILAN_TRY(pack_conv(c, p + "conv1", "", 2, 3, &c->stem, s));
   MILAN_REQUIRE(c->stem.cout == c->d.trunk_width, MILAN_ERR_SHAPE,
@@ -215,26 +245,41 @@ int encoder_finalize(milan_ctx* c, hipStream_t s) {
                        tg->dev, tb->dev, tm->dev, tv->dev, w, c->bn1_scale,
                        c->bn1_shift);
   }
+  const bool basic = kind == MILAN_TRUNK_BASIC;
   for (int li = 0; li < 4; ++li) {
     c->blocks[li].clear();
     for (int bi = 0; bi < c->d.trunk_blocks[li]; ++bi) {
       Bottleneck b;
+      b.basic = basic;
       const std::string q =
           p + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
       const int stride = (bi == 0 && li > 0) ? 2 : 1;
-      MILAN_TRY(pack_conv(c, q + "conv1", q + "bn1", 1, 0, &b.c1, s));
-      MILAN_TRY(pack_conv(c, q + "conv2", q + "bn2", stride, 1, &b.c2, s));
-      MILAN_TRY(pack_conv(c, q + "conv3", q + "bn3", 1, 0, &b.c3, s));
+      MILAN_REQUIRE((find(c, q + "conv3.weight") != nullptr) == !basic,
+                    MILAN_ERR_STATE,
+                    "%s does not look like a %s block (dims.trunk_kind = %d)",
+                    q.c_str(), basic ? "basic" : "bottleneck", kind);
+      if (basic) {
+        // BasicBlock: 3x3 (carries the stride) -> 3x3, expansion 1
+        MILAN_TRY(pack_conv(c, q + "conv1", q + "bn1", stride, 1, &b.c1, s));
+        MILAN_TRY(pack_conv(c, q + "conv2", q + "bn2", 1, 1, &b.c2, s));
+      } else {
+        MILAN_TRY(pack_conv(c, q + "conv1", q + "bn1", 1, 0, &b.c1, s));
+        MILAN_TRY(pack_conv(c, q + "conv2", q + "bn2", stride, 1, &b.c2, s));
+        MILAN_TRY(pack_conv(c, q + "conv3", q + "bn3", 1, 0, &b.c3, s));
+      }
       b.has_down = find(c, q + "downsample.0.weight") != nullptr;
-      MILAN_REQUIRE(b.has_down == (bi == 0), MILAN_ERR_STATE,
-                    "unexpected downsample layout at %s", q.c_str());
+      // torchvision adds a downsample wherever the block changes the shape
+      MILAN_REQUIRE(b.has_down == (bi == 0 && (!basic || li > 0)),
+                    MILAN_ERR_STATE, "unexpected downsample layout at %s",
+                    q.c_str());
       if (b.has_down) {
         MILAN_TRY(pack_conv(c, q + "downsample.0", q + "downsample.1", stride,
                             0, &b.down, s));
-        MILAN_TRY(fuse_c3_down(c, &b, s));
+        if (!basic) MILAN_TRY(fuse_c3_down(c, &b, s));
       }
       c->blocks[li].push_back(b);
     }
+  }
   }
   if (const Tensor* t = find(c, "encoder.mean")) {
     MILAN_CHECK_HIP(hipMemcpyAsync(c->mean, t->dev, 3 * sizeof(float),
@@ -606,11 +651,19 @@ static int encoder_sub_batch() {
   return v;
 }
 
+static void alexnet_workspace_dry(const milan_ctx* c, int n, int H, int W,
+                                  Arena& a);
+
 size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W) {
   Arena a; a.dry = true;
-  EncPlan pl;
   const int sub = encoder_sub_batch();
-  plan(c, n_images < sub ? n_images : sub, H, W, a, &pl);
+  const int n = n_images < sub ? n_images : sub;
+  if (c->d.trunk_kind == MILAN_TRUNK_ALEXNET) {
+    alexnet_workspace_dry(c, n, H, W, a);
+    return a.off;
+  }
+  EncPlan pl;
+  plan(c, n, H, W, a, &pl);
   return a.off;
 }
 
@@ -640,6 +693,9 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
 static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                              const void* masks, int mask_dtype, int n, int H,
                              int W, float* features, Arena& ws, hipStream_t s);
+static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
+                             const void* masks, int mask_dtype, int n, int H,
+                             int W, float* features, Arena& ws, hipStream_t s);
 
 int encoder_run(milan_ctx* c, const void* images, int image_dtype,
                 const void* masks, int mask_dtype, int n, int H, int W,
@@ -666,6 +722,9 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                 "encoder weights were not uploaded");
   MILAN_REQUIRE(n > 0 && H >= 32 && W >= 32, MILAN_ERR_SHAPE,
                 "encode: need n>0 and H,W>=32 (got n=%d H=%d W=%d)", n, H, W);
+  if (c->d.trunk_kind == MILAN_TRUNK_ALEXNET)
+    return alexnet_run_batch(c, images, image_dtype, masks, mask_dtype, n, H, W,
+                             features, ws, s);
   EncPlan pl;
   plan(c, n, H, W, ws, &pl);
   MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
@@ -692,7 +751,8 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   bool split = c->precision == MILAN_PRECISION_SPLIT_F16 && wd % 8 == 0;
   for (int li = 0; li < 4 && split; ++li)
     for (const Bottleneck& b : c->blocks[li])
-      split = split && b.c1.ws && b.c2.ws && b.c3.ws && (!b.has_down || b.down.ws);
+      split = split && b.c1.ws && b.c2.ws && (b.basic || b.c3.ws) &&
+              (!b.has_down || b.down.ws);
   const bool pair_stem = split && c->stem_pair.ws != nullptr;
   const int G = (W + 2) / 2;  // pixel-pair groups per image row
 
@@ -771,6 +831,26 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   for (int li = 0; li < 4; ++li) {
     for (const Bottleneck& b : c->blocks[li]) {
       int h1, w1, h2, w2, h3, w3;
+      if (b.basic) {
+        // BasicBlock (resnet18/34): relu(bn2(conv2(relu(bn1(conv1(x))))) + id)
+        GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
+                                c->zero, &h1, &w1, split);
+        MILAN_TRY(launch_gemm(g1, s));
+        const float* identity = x;
+        if (b.has_down) {
+          int hd, wdn;
+          GemmArgs gd = conv_args(b.down, x, n, h, w, pl.ds, EPI_BIAS, nullptr,
+                                  c->zero, &hd, &wdn, split);
+          MILAN_TRY(launch_gemm(gd, s));
+          identity = pl.ds;
+        }
+        GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, y, EPI_BIAS_RES_RELU,
+                                identity, c->zero, &h3, &w3, split);
+        MILAN_TRY(launch_gemm(g2, s));
+        float* tmp = x; x = y; y = tmp;
+        h = h3; w = w3;
+        continue;
+      }
       GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
                               c->zero, &h1, &w1, split);
       MILAN_TRY(launch_gemm(g1, s));
@@ -810,11 +890,238 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       float* tmp = x; x = y; y = tmp;
       h = h3; w = w3;
     }
-    const int C = wd * 4 << li;
+    const int C = (c->d.trunk_kind == MILAN_TRUNK_BASIC ? wd : wd * 4) << li;
     MILAN_REQUIRE(h == pl.lv.h[li + 1] && w == pl.lv.w[li + 1], MILAN_ERR_SHAPE,
                   "internal: stage %d geometry mismatch", li + 1);
     MILAN_TRY(pool(x, li + 1, C, col));
     col += C;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// 'alexnet' pyramid config (reference src/milan/encoders.py:330-335)
+// ---------------------------------------------------------------------------
+// Taps are torchvision's features.0/3/6/8/10, i.e. the five conv modules.
+// nethook retains `output.detach()` (src/deps/netdissect/nethook.py:226-235),
+// which shares storage with the conv output, and every AlexNet conv is followed
+// by nn.ReLU(inplace=True): what the encoder pools is relu(conv + bias) (pinned
+// by golden G11).  So each conv runs with the bias+ReLU epilogue and its output
+// is both the tap and the next layer's (max-pooled) input.
+
+// 3x3 / stride 2 max-pool over NHWC, `pad` pixels of implicit -inf padding.
+__global__ void maxpool3s2_f32_kernel(const float4* __restrict__ x, int n, int H,
+                                      int W, int C4, int Ho, int Wo, int pad,
+                                      float4* __restrict__ y) {
+  const long total = (long)n * Ho * Wo * C4;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int cc = idx % C4;
+    long t = idx / C4;
+    const int wo = t % Wo; t /= Wo;
+    const int ho = t % Ho;
+    const long img = t / Ho;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * 2 - pad + dy;
+      if (hi < 0 || hi >= H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * 2 - pad + dx;
+        if (wi < 0 || wi >= W) continue;
+        const float4 v = x[((img * H + hi) * W + wi) * C4 + cc];
+        best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+        best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+      }
+    }
+    y[idx] = best;
+  }
+}
+
+// Same, 8 channels per thread, split-format output; input fp32 or split.
+template <bool IN_SPLIT>
+__global__ void maxpool3s2_split_kernel(const float* __restrict__ x, int n, int H,
+                                        int W, int C, int Ho, int Wo, int pad,
+                                        float* __restrict__ y) {
+  const int C8 = C >> 3;
+  const long total = (long)n * Ho * Wo * C8;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int c8 = idx % C8;
+    long t = idx / C8;
+    const int wo = t % Wo; t /= Wo;
+    const int ho = t % Ho;
+    const long img = t / Ho;
+    float best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * 2 - pad + dy;
+      if (hi < 0 || hi >= H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * 2 - pad + dx;
+        if (wi < 0 || wi >= W) continue;
+        const float* p = x + ((img * H + hi) * W + wi) * C + c8 * 8;
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4);
+        float v[8];
+        if constexpr (IN_SPLIT) {
+          const f16x8_t hh = __builtin_bit_cast(f16x8_t, a);
+          const f16x8_t ll = __builtin_bit_cast(f16x8_t, b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (float)hh[e] + (float)ll[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
+      }
+    }
+    f32x4_t hi4, lo4;
+    enc_split8(best, &hi4, &lo4);
+    float* d = y + idx * 8;
+    *reinterpret_cast<f32x4_t*>(d) = hi4;
+    *reinterpret_cast<f32x4_t*>(d + 4) = lo4;
+  }
+}
+
+struct AlexPlan {
+  Levels lv;
+  int hq[2], wq[2];        // max-pooled sizes after conv1 / conv2
+  int C[5];
+  float *in4, *a[5], *q[2];
+  int *list_idx, *list_n;
+  float* list_w;
+};
+
+static void alexnet_plan(const milan_ctx* c, int n, int H, int W, Arena& ar,
+                         AlexPlan* pl) {
+  static const int mult[5] = {1, 3, 6, 4, 4};
+  const int wd = c->d.trunk_width;
+  Levels& lv = pl->lv;
+  lv.h[0] = conv_out(H, 11, 4, 2); lv.w[0] = conv_out(W, 11, 4, 2);
+  pl->hq[0] = conv_out(lv.h[0], 3, 2, 0); pl->wq[0] = conv_out(lv.w[0], 3, 2, 0);
+  lv.h[1] = pl->hq[0]; lv.w[1] = pl->wq[0];          // 5x5 pad 2 keeps the size
+  pl->hq[1] = conv_out(lv.h[1], 3, 2, 0); pl->wq[1] = conv_out(lv.w[1], 3, 2, 0);
+  for (int l = 2; l < 5; ++l) { lv.h[l] = pl->hq[1]; lv.w[l] = pl->wq[1]; }
+  long off = 0;
+  for (int l = 0; l < 5; ++l) { lv.off[l] = off; off += (long)lv.h[l] * lv.w[l]; }
+  lv.per_image = off;
+  for (int l = 0; l < 5; ++l) pl->C[l] = mult[l] * wd;
+  pl->in4 = ar.get<float>((size_t)n * H * W * 4);
+  for (int l = 0; l < 5; ++l)
+    pl->a[l] = ar.get<float>((size_t)n * lv.h[l] * lv.w[l] * pl->C[l]);
+  for (int l = 0; l < 2; ++l)
+    pl->q[l] = ar.get<float>((size_t)n * pl->hq[l] * pl->wq[l] * pl->C[l]);
+  pl->list_idx = ar.get<int>((size_t)n * lv.per_image);
+  pl->list_w = ar.get<float>((size_t)n * lv.per_image);
+  pl->list_n = ar.get<int>((size_t)n * 5);
+}
+
+static void alexnet_workspace_dry(const milan_ctx* c, int n, int H, int W,
+                                  Arena& a) {
+  AlexPlan pl;
+  alexnet_plan(c, n, H, W, a, &pl);
+}
+
+static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
+                             const void* masks, int mask_dtype, int n, int H,
+                             int W, float* features, Arena& ws, hipStream_t s) {
+  AlexPlan pl;
+  alexnet_plan(c, n, H, W, ws, &pl);
+  MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
+                "encode: workspace too small (%zu needed, %zu given)", ws.off,
+                ws.size);
+  MILAN_REQUIRE(pl.hq[1] >= 1 && pl.wq[1] >= 1 &&
+                    pl.lv.h[0] * pl.lv.w[0] <= kMaxLevelPixels,
+                MILAN_ERR_SHAPE, "encode: image %dx%d unsupported by the alexnet "
+                "pyramid", H, W);
+  const int F = c->d.feature_size;
+  if (masks == nullptr || mask_dtype == MILAN_DTYPE_U8)
+    hipLaunchKernelGGL(mask_pyramid_kernel<uint8_t>, dim3(n, 5), dim3(256), 0, s,
+                       (const uint8_t*)masks, H, W, pl.lv, pl.list_idx,
+                       pl.list_w, pl.list_n);
+  else
+    hipLaunchKernelGGL(mask_pyramid_kernel<float>, dim3(n, 5), dim3(256), 0, s,
+                       (const float*)masks, H, W, pl.lv, pl.list_idx, pl.list_w,
+                       pl.list_n);
+  {
+    const long np = (long)n * H * W;
+    const int blocks = (int)((np + 255) / 256 < 8192 ? (np + 255) / 256 : 8192);
+    if (image_dtype == MILAN_DTYPE_U8)
+      hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
+                         s, (const uint8_t*)images, np, H * W, c->mean[0],
+                         c->mean[1], c->mean[2], c->stdv[0], c->stdv[1],
+                         c->stdv[2], (float4*)pl.in4);
+    else
+      hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
+                         (const float*)images, np, H * W, c->mean[0], c->mean[1],
+                         c->mean[2], c->stdv[0], c->stdv[1], c->stdv[2],
+                         (float4*)pl.in4);
+    MILAN_CHECK_HIP(hipGetLastError());
+  }
+  // split-f16 mode from conv2 on (conv1 has Cin = 3: fp32 kernel, fp32 tap)
+  bool split = c->precision == MILAN_PRECISION_SPLIT_F16;
+  for (int l = 0; l < 5; ++l)
+    split = split && pl.C[l] % 8 == 0 && (l == 0 || c->alex[l].ws != nullptr);
+
+  int col = 0;
+  auto pool = [&](int l, bool tap_split) -> int {
+    const int P = pl.lv.h[l] * pl.lv.w[l], C = pl.C[l];
+    if (tap_split)
+      hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
+                         dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
+                         pl.list_w, pl.list_n, features, F, col);
+    else
+      hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(n, (C + 63) / 64),
+                         dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
+                         pl.list_w, pl.list_n, features, F, col);
+    MILAN_CHECK_HIP(hipGetLastError());
+    col += C;
+    return 0;
+  };
+  auto maxpool = [&](int l, bool in_split) -> int {
+    const int C = pl.C[l];
+    const long total = (long)n * pl.hq[l] * pl.wq[l] * (C / (split ? 8 : 4));
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (!split)
+      hipLaunchKernelGGL(maxpool3s2_f32_kernel, dim3(blocks), dim3(256), 0, s,
+                         (const float4*)pl.a[l], n, pl.lv.h[l], pl.lv.w[l], C / 4,
+                         pl.hq[l], pl.wq[l], 0, (float4*)pl.q[l]);
+    else if (in_split)
+      hipLaunchKernelGGL(maxpool3s2_split_kernel<true>, dim3(blocks), dim3(256),
+                         0, s, pl.a[l], n, pl.lv.h[l], pl.lv.w[l], C, pl.hq[l],
+                         pl.wq[l], 0, pl.q[l]);
+    else
+      hipLaunchKernelGGL(maxpool3s2_split_kernel<false>, dim3(blocks), dim3(256),
+                         0, s, pl.a[l], n, pl.lv.h[l], pl.lv.w[l], C, pl.hq[l],
+                         pl.wq[l], 0, pl.q[l]);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+
+  int ho, wo;
+  GemmArgs g0 = conv_args(c->alex[0], pl.in4, n, H, W, pl.a[0], EPI_BIAS_RELU,
+                          nullptr, c->zero, &ho, &wo);
+  MILAN_TRY(launch_gemm(g0, s));
+  MILAN_TRY(pool(0, false));
+  MILAN_TRY(maxpool(0, false));
+  const float* in = pl.q[0];
+  int h = pl.hq[0], w = pl.wq[0];
+  for (int l = 1; l < 5; ++l) {
+    GemmArgs g = conv_args(c->alex[l], in, n, h, w, pl.a[l], EPI_BIAS_RELU,
+                           nullptr, c->zero, &ho, &wo, split);
+    MILAN_REQUIRE(ho == pl.lv.h[l] && wo == pl.lv.w[l], MILAN_ERR_SHAPE,
+                  "internal: alexnet level %d geometry mismatch", l);
+    MILAN_TRY(launch_gemm(g, s));
+    MILAN_TRY(pool(l, split));
+    in = pl.a[l];
+    h = ho; w = wo;
+    if (l == 1) {
+      MILAN_TRY(maxpool(1, split));
+      in = pl.q[1];
+      h = pl.hq[1]; w = pl.wq[1];
+    }
   }
   return 0;
 }

@@ -5,11 +5,11 @@ masks=None) -> (M, *feature_shape), map(dataset) -> TensorDataset;
 encoders.py:23-148) so any subclass -- including a caller's own, like the
 reference's test FakeEncoder -- still plugs into `Decoder`.
 `PyramidConvEncoder` (encoders.py:243-351) is the one pretrained MILAN uses;
-its arithmetic runs in libmilan_hip (`milan_encode`).  Bottleneck ResNet
-configs only (resnet50 / resnet101 / resnet152-shaped); the reference's
-`alexnet` / `resnet18` pyramid configs and `SpatialConvEncoder` use other
-trunks and are out of scope (ValueError, same type the reference raises for
-an unsupported config, encoders.py:265-267).
+its arithmetic runs in libmilan_hip (`milan_encode`).  All four configs of the
+reference's table (encoders.py:326-351) are built: 'alexnet', 'resnet18',
+'resnet50', 'resnet101' (plus the same-shaped resnet34 / resnet152); unknown
+names raise ValueError like the reference (encoders.py:265-267).
+`SpatialConvEncoder` is out of scope.
 """
 from typing import Any, Mapping, Optional, Tuple, Type, Union
 
@@ -98,10 +98,16 @@ class PyramidConvEncoder(Encoder):
         self.kwargs.setdefault('pretrained', True)
         self.width = int(self.kwargs.get('width', 64))
         self.blocks, self.layers = configs[config]
-        self.feature_shape = (61 * self.width,)
+        self.feature_shape = (synthetic.pyramid_feature_size(config,
+                                                             self.width),)
         self.encoder = params.ParamTree()
-        params.build(params.resnet_spec(self.blocks, self.width, 'model.'),
-                     root=self.encoder)
+        if config == 'alexnet':
+            spec = params.alexnet_spec(self.width, 'model.')
+        else:
+            spec = params.resnet_spec(
+                self.blocks, self.width, 'model.',
+                basic=config in synthetic.BASIC_BLOCK_CONFIGS)
+        params.build(spec, root=self.encoder)
         self.register_buffer('mean',
                              torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1))
         self.register_buffer('std', torch.tensor(IMAGENET_STD).view(1, 3, 1, 1))
@@ -140,11 +146,17 @@ class PyramidConvEncoder(Encoder):
 
     @staticmethod
     def configs():
+        """name -> (blocks per stage, retained layer names); reference
+        encoders.py:326-351."""
         layers = ('conv1', 'layer1', 'layer2', 'layer3', 'layer4')
-        return {
+        table = {
             name: (blocks, layers)
             for name, blocks in synthetic.RESNET_BLOCKS.items()
         }
+        table['alexnet'] = ((0, 0, 0, 0),
+                            ('features.0', 'features.3', 'features.6',
+                             'features.8', 'features.10'))
+        return table
 
 
 def parse(key: str) -> Type[Encoder]:

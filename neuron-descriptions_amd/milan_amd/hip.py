@@ -46,7 +46,15 @@ class Dims(ctypes.Structure):
         ('lm_hidden_size', ctypes.c_int32),
         ('lm_embedding_size', ctypes.c_int32),
         ('lm_layers', ctypes.c_int32),
+        ('trunk_kind', ctypes.c_int32),
     ]
+
+
+ABI_VERSION = 2  # MILAN_ABI_VERSION this binding was written against
+
+# milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
+TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET = 0, 1, 2
+_FEATURE_MULT = {TRUNK_BOTTLENECK: 61, TRUNK_BASIC: 16, TRUNK_ALEXNET: 18}
 
 
 _P = ctypes.c_void_p
@@ -121,6 +129,10 @@ def load_library(path: Optional[os.PathLike] = None) -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.milan_abi_version() != ABI_VERSION:
+        raise HipUnavailableError(
+            f'{p} has C-ABI version {lib.milan_abi_version()}, this binding '
+            f'needs {ABI_VERSION} (struct milan_dims differs): rebuild it')
     if path is None:
         _lib = lib
     return lib
@@ -643,8 +655,14 @@ def make_dims(state_dict: Dict[str, torch.Tensor],
     """Derive `milan_dims` from a reference state dict + vocabulary size."""
     d = Dims()
     sd = state_dict
-    enc = 'encoder.encoder.model.conv1.weight'
-    width = sd[enc].shape[0] if enc in sd else None
+    pre = 'encoder.encoder.model.'
+    width = kind = None
+    if pre + 'features.0.weight' in sd:  # 'alexnet' config
+        kind, width = TRUNK_ALEXNET, sd[pre + 'features.0.weight'].shape[0]
+    elif pre + 'conv1.weight' in sd:
+        width = sd[pre + 'conv1.weight'].shape[0]
+        kind = (TRUNK_BOTTLENECK if pre + 'layer1.0.conv3.weight' in sd else
+                TRUNK_BASIC)
     if 'lstm.weight_hh' in sd:
         hidden = sd['lstm.weight_hh'].shape[1]
         emb = sd['embedding.weight'].shape[1]
@@ -653,11 +671,18 @@ def make_dims(state_dict: Dict[str, torch.Tensor],
         vocab = sd['output.1.weight'].shape[0]
     else:
         hidden, emb, att, vocab = 4, 4, 4, n_vocab_tokens + 4
-        feat = 61 * width
+        feat = _FEATURE_MULT[kind] * width
     if width is None:
-        if feat % 61:
-            raise ValueError(f'feature size {feat} is not a pyramid (61*w)')
-        width = feat // 61
+        # decoder-only context (foreign Encoder): any geometry that satisfies
+        # milan_create's feature_size == mult * width check will do
+        for k, mult in _FEATURE_MULT.items():
+            if feat % (4 * mult) == 0:
+                kind, width = k, feat // mult
+                break
+        else:
+            raise ValueError(f'feature size {feat} is not a pyramid '
+                             '(61, 16 or 18 x a multiple of 4)')
+    d.trunk_kind = kind
     if vocab != n_vocab_tokens + 4:
         raise ValueError(
             f'output layer has {vocab} classes but the indexer has '

@@ -49,11 +49,34 @@ def build(spec: Mapping[str, Tuple[Sequence[int], torch.dtype]],
     return root
 
 
+def alexnet_spec(width: int = 64,
+                 prefix: str = '') -> Dict[str, Tuple[Tuple[int, ...],
+                                                      torch.dtype]]:
+    """torchvision-0.12 AlexNet state-dict names and shapes (`features.N`,
+    `classifier.N`; the classifier is in the checkpoint but never read)."""
+    f = torch.float32
+    c = [m * width for m in (1, 3, 6, 4, 4)]
+    spec: Dict[str, Tuple[Tuple[int, ...], torch.dtype]] = {}
+    for idx, cin, cout, k in ((0, 3, c[0], 11), (3, c[0], c[1], 5),
+                              (6, c[1], c[2], 3), (8, c[2], c[3], 3),
+                              (10, c[3], c[4], 3)):
+        spec[f'{prefix}features.{idx}.weight'] = ((cout, cin, k, k), f)
+        spec[f'{prefix}features.{idx}.bias'] = ((cout,), f)
+    hidden = 64 * width
+    for idx, cin, cout in ((1, c[4] * 36, hidden), (4, hidden, hidden),
+                           (6, hidden, 1000)):
+        spec[f'{prefix}classifier.{idx}.weight'] = ((cout, cin), f)
+        spec[f'{prefix}classifier.{idx}.bias'] = ((cout,), f)
+    return spec
+
+
 def resnet_spec(blocks: Sequence[int],
                 width: int = 64,
-                prefix: str = '') -> Dict[str, Tuple[Tuple[int, ...],
-                                                     torch.dtype]]:
-    """torchvision-0.12 bottleneck ResNet state-dict names and shapes."""
+                prefix: str = '',
+                basic: bool = False) -> Dict[str, Tuple[Tuple[int, ...],
+                                                        torch.dtype]]:
+    """torchvision-0.12 ResNet state-dict names and shapes (bottleneck blocks,
+    or BasicBlock for resnet18/34)."""
     f, i64 = torch.float32, torch.int64
     spec: Dict[str, Tuple[Tuple[int, ...], torch.dtype]] = {}
 
@@ -67,6 +90,21 @@ def resnet_spec(blocks: Sequence[int],
     spec[prefix + 'conv1.weight'] = ((width, 3, 7, 7), f)
     bn(prefix + 'bn1', width)
     inplanes = width
+    if basic:
+        for li, n in enumerate(blocks):
+            planes = width * 2**li
+            for bi in range(n):
+                p = f'{prefix}layer{li + 1}.{bi}.'
+                spec[p + 'conv1.weight'] = ((planes, inplanes, 3, 3), f)
+                bn(p + 'bn1', planes)
+                spec[p + 'conv2.weight'] = ((planes, planes, 3, 3), f)
+                bn(p + 'bn2', planes)
+                if bi == 0 and li > 0:
+                    spec[p + 'downsample.0.weight'] = ((planes, inplanes, 1, 1),
+                                                       f)
+                    bn(p + 'downsample.1', planes)
+                inplanes = planes
+        blocks = ()
     for li, n in enumerate(blocks):
         planes = width * 2**li
         for bi in range(n):

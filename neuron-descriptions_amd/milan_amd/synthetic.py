@@ -22,10 +22,30 @@ from typing import Dict, Optional, Sequence, Tuple
 import torch
 
 RESNET_BLOCKS = {
+    'resnet18': (2, 2, 2, 2),
+    'resnet34': (3, 4, 6, 3),
     'resnet50': (3, 4, 6, 3),
     'resnet101': (3, 4, 23, 3),
     'resnet152': (3, 8, 36, 3),
 }
+BASIC_BLOCK_CONFIGS = ('resnet18', 'resnet34')  # torchvision BasicBlock trunks
+# trunk kinds of milan_dims.trunk_kind (include/milan_hip.h)
+TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET = 0, 1, 2
+ALEXNET_CHANNELS = (1, 3, 6, 4, 4)  # x width (64): 64, 192, 384, 256, 256
+
+
+def trunk_kind(config: str) -> int:
+    if config == 'alexnet':
+        return TRUNK_ALEXNET
+    return TRUNK_BASIC if config in BASIC_BLOCK_CONFIGS else TRUNK_BOTTLENECK
+
+
+def pyramid_feature_size(config: str, width: int = 64) -> int:
+    """Sum of the five tap widths (encoders.py:330-350: 1152 / 1024 / 3904)."""
+    kind = trunk_kind(config)
+    if kind == TRUNK_ALEXNET:
+        return sum(ALEXNET_CHANNELS) * width
+    return (16 if kind == TRUNK_BASIC else 61) * width
 PYRAMID_FEATURES = 64 + 256 + 512 + 1024 + 2048  # encoders.py:346-350
 
 
@@ -70,6 +90,22 @@ def resnet_state_dict(config: str = 'resnet101',
     sd[prefix + 'conv1.weight'] = _conv(g, width, 3, 7)
     _bn(g, sd, prefix + 'bn1', width, var=3.5)
     inplanes = width
+    if config in BASIC_BLOCK_CONFIGS:
+        # BasicBlock: 3x3 (carries the stride) -> 3x3, expansion 1; downsample
+        # only where the shape changes (not in layer1)
+        for li, nblocks in enumerate(blocks):
+            planes = width * (2**li)
+            for bi in range(nblocks):
+                p = f'{prefix}layer{li + 1}.{bi}.'
+                sd[p + 'conv1.weight'] = _conv(g, planes, inplanes, 3)
+                _bn(g, sd, p + 'bn1', planes)
+                sd[p + 'conv2.weight'] = _conv(g, planes, planes, 3)
+                _bn(g, sd, p + 'bn2', planes, gamma=0.25)
+                if bi == 0 and li > 0:
+                    sd[p + 'downsample.0.weight'] = _conv(g, planes, inplanes, 1)
+                    _bn(g, sd, p + 'downsample.1', planes)
+                inplanes = planes
+        blocks = ()
     for li, nblocks in enumerate(blocks):
         planes = width * (2**li)
         for bi in range(nblocks):
@@ -91,6 +127,30 @@ def resnet_state_dict(config: str = 'resnet101',
         sd[prefix + 'fc.weight'] = torch.randn(1000, inplanes,
                                                generator=g) * 0.01
         sd[prefix + 'fc.bias'] = torch.zeros(1000)
+    return sd
+
+
+def alexnet_state_dict(seed: int = 0,
+                       prefix: str = '',
+                       width: int = 64,
+                       with_classifier: bool = True
+                       ) -> Dict[str, torch.Tensor]:
+    """Synthetic torchvision-style AlexNet state dict (`features.N.*` keys,
+    the factory behind the reference's 'alexnet' config, encoders.py:330-335).
+    Convs carry biases; there is no BatchNorm."""
+    g = _gen(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    ch = [c * width for c in ALEXNET_CHANNELS]
+    spec = ((0, 3, ch[0], 11), (3, ch[0], ch[1], 5), (6, ch[1], ch[2], 3),
+            (8, ch[2], ch[3], 3), (10, ch[3], ch[4], 3))
+    for idx, cin, cout, k in spec:
+        sd[f'{prefix}features.{idx}.weight'] = _conv(g, cout, cin, k)
+        sd[f'{prefix}features.{idx}.bias'] = 0.1 * torch.randn(cout, generator=g)
+    if with_classifier:  # computed and discarded by the reference
+        for idx, cin, cout in ((1, ch[4] * 36, 64), (4, 64, 64), (6, 64, 1000)):
+            sd[f'{prefix}classifier.{idx}.weight'] = torch.randn(
+                cout, cin, generator=g) * 0.01
+            sd[f'{prefix}classifier.{idx}.bias'] = torch.zeros(cout)
     return sd
 
 
@@ -166,16 +226,20 @@ def milan_state_dict(vocab_size: int,
                      width: int = 64,
                      **decoder_kwargs) -> Dict[str, torch.Tensor]:
     """Full synthetic `Decoder.state_dict()` (SURVEY.md a17 layout)."""
-    feature_size = (1 + 4 + 8 + 16 + 32) * width
+    feature_size = pyramid_feature_size(config, width)
     sd = decoder_state_dict(vocab_size,
                             feature_size=feature_size,
                             seed=seed,
                             **decoder_kwargs)
-    sd.update(
-        resnet_state_dict(config,
-                          seed=seed,
-                          prefix='encoder.encoder.model.',
-                          width=width))
+    if config == 'alexnet':
+        sd.update(alexnet_state_dict(seed=seed, width=width,
+                                     prefix='encoder.encoder.model.'))
+    else:
+        sd.update(
+            resnet_state_dict(config,
+                              seed=seed,
+                              prefix='encoder.encoder.model.',
+                              width=width))
     # encoders.py:282-284 buffers.
     sd['encoder.mean'] = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     sd['encoder.std'] = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)

@@ -41,3 +41,16 @@ def forced_goldens():
 def forced_meta():
     with open(GOLDEN_DIR / 'reference_goldens_forced.json') as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def trunk_goldens():
+    """Encoder goldens of the 'resnet18' / 'alexnet' configs
+    (make_golden_trunks.py)."""
+    return torch.load(GOLDEN_DIR / 'reference_goldens_trunks.pt')
+
+
+@pytest.fixture(scope='session')
+def trunk_meta():
+    with open(GOLDEN_DIR / 'reference_goldens_trunks.json') as f:
+        return json.load(f)

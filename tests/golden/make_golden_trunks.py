@@ -1,0 +1,158 @@
+"""Generate encoder goldens for the reference's other pyramid configs.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_trunks.py
+
+`PyramidConvEncoder.configs()` (src/milan/encoders.py:326-351) offers
+'alexnet', 'resnet18', 'resnet50' and 'resnet101'; make_golden.py covers the
+bottleneck ResNets.  This script runs the REFERENCE encoder code (nethook
+taps, normalisation, bilinear mask resize, isclose rule, pooling) on the two
+remaining configs.  torchvision is not installed, so -- as in make_golden.py
+-- the trunk modules are torchvision-0.12-shaped stand-ins with the same
+module tree (`features.N`, `layerN.M.convK`), loaded with seeded weights.
+
+Outputs: reference_goldens_trunks.pt / .json (data only).
+"""
+import json
+import pathlib
+import sys
+
+import torch
+from torch import nn
+
+HERE = pathlib.Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'neuron-descriptions_amd'))
+sys.path.insert(0, str(HERE))
+
+import make_golden  # noqa: E402
+from milan_amd import synthetic  # noqa: E402
+
+
+class _BasicBlock(nn.Module):
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class _TVBasicResNet(nn.Module):
+    """torchvision-0.12-shaped BasicBlock ResNet (resnet18/34)."""
+
+    def __init__(self, blocks, width=64, pretrained=False, **_):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        inplanes = width
+        for li, n in enumerate(blocks):
+            planes = width * 2**li
+            layers = []
+            for bi in range(n):
+                stride = 2 if (bi == 0 and li > 0) else 1
+                ds = None
+                if stride != 1 or inplanes != planes:
+                    ds = nn.Sequential(
+                        nn.Conv2d(inplanes, planes, 1, stride, bias=False),
+                        nn.BatchNorm2d(planes))
+                layers.append(_BasicBlock(inplanes, planes, stride, ds))
+                inplanes = planes
+            setattr(self, f'layer{li + 1}', nn.Sequential(*layers))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(inplanes, 1000)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+class _TVAlexNet(nn.Module):
+    """torchvision-0.12-shaped AlexNet; `width` scales the channel counts."""
+
+    def __init__(self, width=64, pretrained=False, **_):
+        super().__init__()
+        c = [m * width for m in synthetic.ALEXNET_CHANNELS]
+        self.features = nn.Sequential(
+            nn.Conv2d(3, c[0], 11, 4, 2), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2),
+            nn.Conv2d(c[0], c[1], 5, padding=2), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2),
+            nn.Conv2d(c[1], c[2], 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(c[2], c[3], 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(c[3], c[4], 3, padding=1), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2))
+        self.avgpool = nn.AdaptiveAvgPool2d((6, 6))
+        self.classifier = nn.Sequential(
+            nn.Dropout(), nn.Linear(c[4] * 36, 64), nn.ReLU(inplace=True),
+            nn.Dropout(), nn.Linear(64, 64), nn.ReLU(inplace=True),
+            nn.Linear(64, 1000))
+
+    def forward(self, x):
+        x = self.avgpool(self.features(x))
+        return self.classifier(torch.flatten(x, 1))
+
+
+def main():
+    torch.set_num_threads(8)
+    _, encoders, _, _, _, renormalize = make_golden.import_reference()
+    tvm = sys.modules['torchvision.models']
+    tvm.resnet18 = lambda **kw: _TVBasicResNet(
+        synthetic.RESNET_BLOCKS['resnet18'], **kw)
+    tvm.alexnet = lambda **kw: _TVAlexNet(**kw)
+    ren = renormalize.renormalizer(source='byte', target='pt')
+    out, meta = {}, {}
+
+    def run(config, width, size, m, seed, tag):
+        if config == 'alexnet':
+            sd = synthetic.alexnet_state_dict(seed=seed, width=width)
+        else:
+            sd = synthetic.resnet_state_dict(config, seed=seed, width=width)
+        enc = encoders.PyramidConvEncoder(config=config, pretrained=False,
+                                          width=width)
+        enc.encoder.model.load_state_dict(sd, strict=True)
+        enc.eval()
+        images_u8, masks_u8 = synthetic.exemplars(1, k=m, size=size,
+                                                  seed=seed + 10, zero_every=0)
+        masks_u8 = masks_u8.clone()
+        masks_u8[0, 1] = 0  # all-zero mask -> exact zero row
+        masks_u8[0, 2] = 0
+        masks_u8[0, 2, 0, size // 3, size // 2] = 1  # single pixel
+        images = ren(images_u8.float().view(-1, 3, size, size))
+        masks = masks_u8.float().view(-1, 1, size, size)
+        with torch.no_grad():
+            feats = enc(images, masks)
+        assert feats.shape[1] == synthetic.pyramid_feature_size(config, width)
+        out[f'g11_{tag}_features'] = feats.clone()
+        out[f'g11_{tag}_masks_u8'] = masks_u8.clone()
+        meta[f'g11_{tag}'] = dict(config=config, width=width, size=size, m=m,
+                                  weight_seed=seed, image_seed=seed + 10)
+
+    run('resnet18', 16, 96, 4, 21, 'r18_96')
+    run('resnet18', 64, 224, 3, 22, 'r18_full')   # real resnet18 dims (F=1024)
+    run('alexnet', 16, 100, 4, 23, 'alex_100')
+    run('alexnet', 64, 224, 3, 24, 'alex_full')   # real alexnet dims (F=1152)
+
+    torch.save(out, HERE / 'reference_goldens_trunks.pt')
+    with open(HERE / 'reference_goldens_trunks.json', 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    size = (HERE / 'reference_goldens_trunks.pt').stat().st_size
+    print(f'wrote {len(out)} tensors, {size / 1e3:.0f} kB')
+
+
+if __name__ == '__main__':
+    main()

@@ -34,7 +34,9 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in milan_hip.h but not exported'
     assert sorted(hip.SIGNATURES) == syms
-    assert lib.milan_abi_version() == 1
+    header_version = int(re.search(r'#define MILAN_ABI_VERSION (\d+)',
+                                   HEADER.read_text()).group(1))
+    assert lib.milan_abi_version() == header_version == hip.ABI_VERSION
     out = subprocess.run(['nm', '-D', '--defined-only', str(hip.LIB_PATH)],
                          capture_output=True, text=True, check=True).stdout
     exported = sorted(
