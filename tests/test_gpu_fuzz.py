@@ -1,0 +1,92 @@
+"""Seeded differential fuzzing of the HIP path against the CPU oracle: random
+(small) model geometries, image sizes, exemplar counts, beam sizes, lengths,
+vocabulary sizes, trunk kinds, MI on/off and temperatures -- the shapes nobody
+thought to write a dedicated test for (odd image sizes, V not a multiple of 4,
+beam == V, k == 1, a single neuron, widths that defeat the split-f16 path)."""
+import random
+
+import pytest
+import torch
+
+from milan_amd import hip, synthetic
+from oracle import milan_oracle as O
+from tests.test_gpu_parity import _check_beams, assert_tokens_match, close
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = ['resnet50', 'resnet18', 'alexnet']
+
+
+def draw(seed):
+    r = random.Random(seed)
+    config = r.choice(CONFIGS)
+    width = r.choice([8, 16, 32])
+    if config == 'alexnet':
+        size_h, size_w = r.randint(64, 110), r.randint(64, 110)
+    else:
+        size_h, size_w = r.randint(33, 97), r.randint(33, 97)
+    nv = r.choice([9, 21, 37, 64, 130, 700])
+    hidden = r.choice([16, 32, 64])
+    emb = r.choice([8, 16, 32])
+    return dict(
+        config=config, width=width, h=size_h, w=size_w, nv=nv, hidden=hidden,
+        emb=emb, k=r.randint(1, 6), n=r.randint(1, 5),
+        length=r.randint(1, 9), beam=r.randint(1, min(nv + 4, 12)),
+        mi=r.random() < 0.4, temperature=r.choice([0.1, 0.2, 0.5]),
+        precision=r.choice(['f32', 'split_f16']),
+        zero_every=r.choice([0, 3]))
+
+
+@pytest.mark.parametrize('seed', range(28))
+def test_fuzz_encode_and_decode(seed):
+    dev = hip.require_device('cuda')
+    p = draw(1000 + seed)
+    blocks = synthetic.RESNET_BLOCKS.get(p['config'], (0, 0, 0, 0))
+    sd = synthetic.milan_state_dict(p['nv'] + 4, config=p['config'],
+                                    seed=seed, width=p['width'],
+                                    hidden_size=p['hidden'],
+                                    embedding_size=p['emb'],
+                                    lm_hidden_size=p['hidden'],
+                                    lm_embedding_size=p['emb'])
+    ctx = hip.Context(hip.make_dims(sd, p['nv'], blocks=blocks), sd, dev)
+    ctx.set_precision(p['precision'])
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randint(0, 256, (p['n'], p['k'], 3, p['h'], p['w']),
+                           dtype=torch.uint8, generator=g)
+    masks = (torch.rand(p['n'], p['k'], 1, p['h'], p['w'], generator=g) >
+             0.7).to(torch.uint8)
+    if p['zero_every']:
+        masks.view(-1, 1, p['h'], p['w'])[::p['zero_every']] = 0
+    feats = O.encode(O.byte_to_float(images), masks.float(), sd, blocks=blocks)
+    nv, length, beam = p['nv'], p['length'], p['beam']
+
+    # encoder (the fused call also returns the features it decoded from)
+    out = ctx.describe(images, masks, hip.GREEDY, length, 1, p['mi'],
+                       p['temperature'], want_full=True, want_features=True)
+    close(out['features'], feats, 2e-3, 2e-4)
+
+    # decode from the ORACLE's features so both sides see identical inputs
+    want = O.forward(feats, sd, nv, 'greedy', length=length, mi=p['mi'],
+                     temperature=p['temperature'])
+    got = ctx.decode(feats, hip.GREEDY, length, 1, p['mi'], p['temperature'])
+    top2 = want['predictions'].topk(2, dim=-1).values
+    assert_tokens_match(got['tokens'], want['tokens'],
+                        top2[..., 0] - top2[..., 1], what=str(p))
+    if torch.equal(got['tokens'].cpu(), want['tokens']):
+        close(got['predictions'], want['predictions'], 1e-4, 5e-4)
+        close(got['attentions'], want['attentions'], 1e-4, 1e-5)
+        close(got['scores'], want['scores'], 1e-4, 3e-3)
+
+    want_t, want_s = O.beam_search(feats, sd, nv, nv + 1, length, beam,
+                                   mi=p['mi'], temperature=p['temperature'])
+    strategy = hip.BEAM if p['mi'] else hip.RERANK
+    got_b = ctx.decode(feats, strategy, length, beam, p['mi'],
+                       p['temperature'])
+    tp = want_t.shape[2]
+    assert int(got_b['out_len'][0]) == tp, p
+    _check_beams(got_b, want_t, want_s, tp)
+    if not p['mi'] and torch.equal(got_b['beam_tokens'].cpu()[:, :, :tp],
+                                   want_t):
+        t, s, _ = O.rerank(want_t, want_s, sd, nv, nv + 1, p['temperature'])
+        close(got_b['scores'], s, 1e-4, 3e-3)
+    ctx.close()
