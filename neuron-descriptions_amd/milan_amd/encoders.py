@@ -108,11 +108,43 @@ class PyramidConvEncoder(Encoder):
                 self.blocks, self.width, 'model.',
                 basic=config in synthetic.BASIC_BLOCK_CONFIGS)
         params.build(spec, root=self.encoder)
+        if not self.kwargs['pretrained']:
+            self._random_init()
         self.register_buffer('mean',
                              torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1))
         self.register_buffer('std', torch.tensor(IMAGENET_STD).view(1, 3, 1, 1))
         self._ctx: Optional[hip.Context] = None
         self._ctx_key = None
+
+    def _random_init(self) -> None:
+        """`pretrained=False`: what the torchvision factories leave behind --
+        ResNets: Kaiming-normal (fan_out) convs, BatchNorm weight 1 / bias 0 /
+        mean 0 / var 1; AlexNet: PyTorch's default Conv2d/Linear init
+        (uniform +-1/sqrt(fan_in) for weights and biases).  The random stream
+        is torch's global generator, not torchvision's exact draw order.
+        (`pretrained=True`, the reference default, downloads ImageNet weights;
+        there is no network here: tensors stay zero until a checkpoint is
+        loaded.)"""
+        resnet = self.config != 'alexnet'
+        with torch.no_grad():
+            for name, t in list(self.encoder.named_parameters()) + list(
+                    self.encoder.named_buffers()):
+                leaf = name.rsplit('.', 1)[-1]
+                if t.dim() >= 2:  # conv / linear weight
+                    fan_in = t[0].numel()
+                    if resnet and t.dim() == 4:
+                        fan_out = t.shape[0] * t.shape[2] * t.shape[3]
+                        t.normal_(0.0, (2.0 / fan_out)**0.5)
+                    else:
+                        t.uniform_(-fan_in**-0.5, fan_in**-0.5)
+                elif leaf == 'running_var' or (leaf == 'weight' and resnet):
+                    t.fill_(1)  # BatchNorm scale / variance
+                elif leaf == 'bias' and not resnet:
+                    weight = dict(self.encoder.named_parameters())[
+                        name[:-len('bias')] + 'weight']
+                    bound = weight[0].numel()**-0.5
+                    t.uniform_(-bound, bound)
+                # everything else (BN bias / mean, counters) stays zero
 
     # -- HIP context (encoder used stand-alone, e.g. Encoder.map) -------------
     def _context(self) -> hip.Context:
