@@ -115,6 +115,11 @@ class Indexer:
             return self.tokens[token]
         return self.ids[token]
 
+    def __contains__(self, token) -> bool:
+        if isinstance(token, int):
+            return 0 <= token < len(self)
+        return token in self.ids
+
     # -- tokens -> ids (reference lang.py:331-514) ------------------------------
     def __call__(self, texts, **kwargs):
         """Tokenize then index.  `tokenize` is the spaCy-backed `Tokenizer` in
@@ -275,3 +280,15 @@ class LazyCaptions(Sequence):
 
     def __repr__(self):
         return f'LazyCaptions({len(self)} x {self._tokens.shape[1]})'
+
+
+def join(texts: Any, delimiter: str = ' ') -> str:
+    """A string, or an iterable of strings joined by `delimiter` (sets in
+    sorted order); anything else is a ValueError (reference lang.py:781-800)."""
+    if isinstance(texts, (set, frozenset)):
+        texts = tuple(sorted(texts))
+    if isinstance(texts, (list, tuple)):
+        texts = delimiter.join(texts)
+    if not isinstance(texts, str):
+        raise ValueError(f'unknown annotation type: {type(texts).__name__}')
+    return texts
