@@ -35,7 +35,18 @@ class TopImagesDataset(data.Dataset):
                  root: Union[str, pathlib.Path],
                  name: Optional[str] = None,
                  layers: Optional[Iterable[Union[str, int]]] = None,
+                 device: Optional[Union[str, torch.device]] = None,
+                 transform_images=None,
+                 transform_masks=None,
+                 display_progress: bool = True,
                  mmap: bool = True):
+        """Same arguments as the reference (datasets.py:96-103) plus `mmap`.
+        `device` / `transform_*` are applied when a sample is handed out (the
+        arrays themselves stay memory-mapped uint8); `display_progress` is
+        accepted for compatibility -- opening memory maps takes no time."""
+        self.device = device
+        self.transform_images = transform_images
+        self.transform_masks = transform_masks
         root = pathlib.Path(root)
         if not root.is_dir():
             raise FileNotFoundError(f'root directory not found: {root}')
@@ -77,7 +88,10 @@ class TopImagesDataset(data.Dataset):
             self.images_by_layer[layer] = images
             self.masks_by_layer[layer] = masks
             self.units_by_layer[layer] = units
-            self._index += [(layer, i) for i in range(len(images))]
+            # the reference zips (units, images, masks): a units file shorter
+            # than the arrays truncates the layer (datasets.py:201-204)
+            self._index += [(layer, i)
+                            for i in range(min(len(units), len(images)))]
         shapes = {self.images_by_layer[l].shape[1:] for l in self.layers}
         if len(shapes) != 1:
             raise ValueError(f'layers disagree on (k, 3, H, W): {shapes}')
@@ -89,12 +103,39 @@ class TopImagesDataset(data.Dataset):
         layer, i = self._index[index]
         images = torch.from_numpy(numpy.array(self.images_by_layer[layer][i]))
         masks = torch.from_numpy(numpy.array(self.masks_by_layer[layer][i]))
+        return self._sample(layer, int(self.units_by_layer[layer][i]), images,
+                            masks)
+
+    def _sample(self, layer, unit, images, masks, transform=True) -> TopImages:
         # reference datasets.py:191-197: float, images * float32(1/255)
         mul = torch.tensor(1.0 / 255.0, dtype=torch.float64).to(torch.float32)
-        return TopImages(layer=layer,
-                         unit=int(self.units_by_layer[layer][i]),
-                         images=images.float().mul(mul),
-                         masks=masks.float())
+        images, masks = images.float().mul(mul), masks.float()
+        if self.device is not None:
+            images, masks = images.to(self.device), masks.to(self.device)
+        if transform and self.transform_images is not None:
+            images = self.transform_images(images)
+        if transform and self.transform_masks is not None:
+            masks = self.transform_masks(masks)
+        return TopImages(layer=layer, unit=unit, images=images, masks=masks)
+
+    @property
+    def samples(self):
+        """Lazy view with the reference's `dataset.samples` list interface."""
+        return _Samples(self)
+
+    @property
+    def k(self) -> int:
+        """The "k" in "top-k images"."""
+        assert len(self) > 0, 'empty dataset?'
+        layer, _ = self._index[0]
+        return int(self.images_by_layer[layer].shape[1])
+
+    def unit(self, index: int) -> Tuple[str, int]:
+        layer, i = self._index[index]
+        return layer, int(self.units_by_layer[layer][i])
+
+    def units(self, indices) -> Tuple[Tuple[str, int], ...]:
+        return tuple(self.unit(index) for index in indices)
 
     def slice_uint8(self, lo: int, hi: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Samples [lo, hi) as uint8 (n,k,3,H,W) / (n,k,1,H,W) CPU tensors."""
@@ -118,7 +159,31 @@ class TopImagesDataset(data.Dataset):
             raise KeyError(f'layer "{layer}" does not exist')
         if unit >= len(self.images_by_layer[layer]):
             raise KeyError(f'layer "{layer}" has no unit {unit}')
-        return self[self._index.index((layer, unit))]
+        # positional, untransformed, like the reference (datasets.py:252-259)
+        return self._sample(
+            layer, unit,
+            torch.from_numpy(numpy.array(self.images_by_layer[layer][unit])),
+            torch.from_numpy(numpy.array(self.masks_by_layer[layer][unit])),
+            transform=False)
+
+
+class _Samples:
+    """Sequence view over a TopImagesDataset (materialises one sample at a
+    time instead of the reference's list of float tensors)."""
+
+    def __init__(self, dataset: TopImagesDataset):
+        self.dataset = dataset
+
+    def __len__(self) -> int:
+        return len(self.dataset)
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return [self.dataset[i] for i in range(*index.indices(len(self)))]
+        return self.dataset[index]
+
+    def __iter__(self):
+        return (self.dataset[i] for i in range(len(self)))
 
 
 def load(key: str, path: Optional[Union[str, pathlib.Path]] = None,

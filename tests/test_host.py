@@ -271,7 +271,11 @@ def test_top_images_dataset_contract(tmp_path):
     mul = torch.tensor(1 / 255, dtype=torch.float64).float()
     assert torch.equal(im[3].float().mul(mul), s.images)
     assert torch.equal(mk[3].float(), s.masks)
-    assert ds.lookup('layer2', 1).unit == 9
+    # lookup is positional and echoes the key it was given, like the reference
+    # (datasets.py:252-259)
+    found = ds.lookup('layer2', 1)
+    assert found.unit == 1 and torch.equal(found.images, s.images)
+    assert ds.k == 5 and ds.unit(4) == ('layer2', 9)
     with pytest.raises(KeyError):
         ds.lookup('nope', 0)
     with pytest.raises(FileNotFoundError):
