@@ -187,10 +187,12 @@ struct milan_ctx {
   float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   // decoder
   milan::LinearW init_h, init_c, q2h, k2h, gate, lstm_ih, lstm_hh, out;
+  milan::LinearW lstm_cat;                   // [W_ih | W_hh] along K (split mode)
   float *att_w = nullptr, *att_b = nullptr;  // attend.output.0: [A], [1]
   float* embedding = nullptr;                // [V][E]
   // language model
   std::vector<milan::LinearW> lm_ih, lm_hh;  // per layer
+  std::vector<milan::LinearW> lm_cat;        // [W_ih | W_hh] per layer
   milan::LinearW lm_out;
   float* lm_embedding = nullptr;
 };

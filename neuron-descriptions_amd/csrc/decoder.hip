@@ -82,6 +82,40 @@ static int pack_linear(milan_ctx* c, const std::string& wname,
   return 0;
 }
 
+// [W_a | W_b] along K, bias b_a + b_b: an LSTM's two gate products
+// x W_ih^T + h W_hh^T as ONE GEMM over the concatenated operand [x | h]
+// (split-f16 mode, where both operands are converted into one scratch matrix
+// anyway).  Leaves out->ws null for shapes the split path does not cover.
+__global__ void cat_rows_kernel(const float* __restrict__ a, int ka,
+                                const float* __restrict__ b, int kb, int n,
+                                float* __restrict__ out) {
+  const int kt = ka + kb;
+  const long total = (long)n * kt;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int r = idx / kt, col = idx - (long)r * kt;
+    out[idx] = col < ka ? a[(long)r * ka + col] : b[(long)r * kb + (col - ka)];
+  }
+}
+static int cat_linear(milan_ctx* c, const LinearW& a, const LinearW& b,
+                      LinearW* out, hipStream_t s) {
+  *out = LinearW();
+  if (a.n != b.n || a.k % 32 || b.k % 32 || a.kp != a.k || b.kp != b.k ||
+      !a.b || !b.b)
+    return 0;
+  out->n = a.n; out->k = out->kp = a.k + b.k;
+  MILAN_TRY(dev_alloc(c, (void**)&out->w, sizeof(float) * (size_t)out->n * out->kp));
+  MILAN_TRY(dev_alloc(c, (void**)&out->b, sizeof(float) * out->n));
+  const long total = (long)out->n * out->kp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cat_rows_kernel, dim3(blocks), dim3(256), 0, s, a.w, a.k, b.w,
+                     b.k, out->n, out->w);
+  hipLaunchKernelGGL(add_vec_kernel, dim3((out->n + 255) / 256), dim3(256), 0, s,
+                     a.b, b.b, out->n, out->b);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return make_split_weight(c, out->w, out->n, out->kp, &out->ws, &out->ws_inv, s);
+}
+
 int decoder_finalize(milan_ctx* c, hipStream_t s) {
   if (!find(c, "lstm.weight_ih")) return 0;  // encoder-only context
   const milan_dims& d = c->d;
@@ -100,6 +134,7 @@ int decoder_finalize(milan_ctx* c, hipStream_t s) {
   MILAN_TRY(pack_linear(c, "lstm.weight_hh", "lstm.bias_hh", 4 * H, H,
                         &c->lstm_hh, s));
   MILAN_TRY(pack_linear(c, "output.1.weight", "output.1.bias", V, H, &c->out, s));
+  MILAN_TRY(cat_linear(c, c->lstm_ih, c->lstm_hh, &c->lstm_cat, s));
   {
     const Tensor *w = find(c, "attend.output.0.weight"),
                  *b = find(c, "attend.output.0.bias"),
@@ -116,12 +151,14 @@ int decoder_finalize(milan_ctx* c, hipStream_t s) {
     const int Hl = d.lm_hidden_size, El = d.lm_embedding_size;
     c->lm_ih.resize(d.lm_layers);
     c->lm_hh.resize(d.lm_layers);
+    c->lm_cat.resize(d.lm_layers);
     for (int l = 0; l < d.lm_layers; ++l) {
       const std::string sfx = "_l" + std::to_string(l);
       MILAN_TRY(pack_linear(c, "lm.lstm.weight_ih" + sfx, "lm.lstm.bias_ih" + sfx,
                             4 * Hl, l == 0 ? El : Hl, &c->lm_ih[l], s));
       MILAN_TRY(pack_linear(c, "lm.lstm.weight_hh" + sfx, "lm.lstm.bias_hh" + sfx,
                             4 * Hl, Hl, &c->lm_hh[l], s));
+      MILAN_TRY(cat_linear(c, c->lm_ih[l], c->lm_hh[l], &c->lm_cat[l], s));
     }
     MILAN_TRY(pack_linear(c, "lm.output.0.weight", "lm.output.0.bias", V, Hl,
                           &c->lm_out, s));
@@ -862,6 +899,30 @@ static int lin(milan_ctx* c, const float* A, long lda, const LinearW& w, float* 
   return launch_gemm(g, s);
 }
 
+// C = A1 W1^T + A2 W2^T + b1 + b2 (an LSTM's gate pre-activations).  Split
+// mode with a concatenated weight: both operands are converted side by side
+// into one scratch matrix [A1 | A2] and multiplied by [W1 | W2] in ONE launch
+// (no second GEMM, no read-modify-write of C); otherwise two GEMMs, the second
+// accumulating into the first.
+static int lin_pair(milan_ctx* c, const float* A1, long lda1, const LinearW& w1,
+                    const float* A2, long lda2, const LinearW& w2,
+                    const LinearW& cat, float* C, int ldc, int M,
+                    hipStream_t s) {
+  if (c->precision == MILAN_PRECISION_SPLIT_F16 && cat.ws && c->scratch &&
+      (size_t)M * cat.k <= c->scratch_floats) {
+    MILAN_TRY(launch_f32_to_split(A1, lda1, c->scratch, cat.k, M, w1.k, 1.f, s));
+    MILAN_TRY(launch_f32_to_split(A2, lda2, c->scratch + w1.k, cat.k, M, w2.k,
+                                  1.f, s));
+    GemmArgs g = linear_args(c->scratch, cat.k, cat.ws, cat.b, C, ldc, M, cat.n,
+                             cat.k, EPI_BIAS, c->zero);
+    g.a_split = 1;
+    g.acc_scale = cat.ws_inv;
+    return launch_gemm(g, s);
+  }
+  MILAN_TRY(lin(c, A1, lda1, w1, C, ldc, M, EPI_BIAS, s));
+  return lin(c, A2, lda2, w2, C, ldc, M, EPI_BIAS_ADD, s, C, ldc);
+}
+
 struct LmState {  // [layers][rows][Hl]
   float *h = nullptr, *c = nullptr;
   long rows = 0;
@@ -882,8 +943,8 @@ static int lm_step(milan_ctx* c, const int64_t* tok, int rows, LmState& st,
     const float* cl = st.c + (long)l * st.rows * Hl;
     float* hn = nx.h + (long)l * nx.rows * Hl;
     float* cn = nx.c + (long)l * nx.rows * Hl;
-    MILAN_TRY(lin(c, in, in_dim, c->lm_ih[l], gates, 4 * Hl, rows, EPI_BIAS, s));
-    MILAN_TRY(lin(c, hl, Hl, c->lm_hh[l], gates, 4 * Hl, rows, EPI_BIAS_ADD, s, gates, 4 * Hl));
+    MILAN_TRY(lin_pair(c, in, in_dim, c->lm_ih[l], hl, Hl, c->lm_hh[l],
+                       c->lm_cat[l], gates, 4 * Hl, rows, s));
     hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * Hl)),
                        dim3(256), 0, s, gates, cl, rows, Hl, hn, cn);
     in = hn;
@@ -932,7 +993,8 @@ static void dec_plan(const milan_ctx* c, int n, int k, int beam, int T, bool lm,
   b->len1 = a.get<int32_t>(2 * (size_t)n + 2);
   {
     const size_t rows = R > (size_t)n * k ? R : (size_t)n * k;
-    b->scratch_floats = rows * (size_t)(E + F);
+    // widest split-format A operand: the LSTM's concatenated [x | h]
+    b->scratch_floats = rows * (size_t)(E + F + d.hidden_size);
     b->scratch = a.get<float>(b->scratch_floats);
   }
   b->lm_logits = nullptr;
@@ -1018,8 +1080,8 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
   MILAN_TRY(lin(c, h, H, c->gate, b->x + E, ldx, rows, EPI_BIAS_SIGMUL, s, b->ctx, F));
   hipLaunchKernelGGL(embed_kernel, dim3(nblk((long)rows * E)), dim3(256), 0, s,
                      c->embedding, tok, rows, E, b->x, ldx);
-  MILAN_TRY(lin(c, b->x, ldx, c->lstm_ih, b->gates, 4 * H, rows, EPI_BIAS, s));
-  MILAN_TRY(lin(c, h, H, c->lstm_hh, b->gates, 4 * H, rows, EPI_BIAS_ADD, s, b->gates, 4 * H));
+  MILAN_TRY(lin_pair(c, b->x, ldx, c->lstm_ih, h, H, c->lstm_hh, c->lstm_cat,
+                     b->gates, 4 * H, rows, s));
   hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * H)), dim3(256),
                      0, s, b->gates, cc, rows, H, hn, cn);
   MILAN_TRY(lin(c, hn, H, c->out, b->logits, V, rows, EPI_BIAS, s));
