@@ -476,7 +476,6 @@ struct Levels {
   long per_image;
 };
 
-static constexpr int kMaxLevelPixels = 12800;
 
 template <typename T>
 __global__ __launch_bounds__(256) void mask_pyramid_kernel(
@@ -486,31 +485,30 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
   // every product/sum below is rounded as written (ATen's scalar formula), the
   // same for the uint8 and float instantiations
 #pragma clang fp contract(off)
-  __shared__ float wts[kMaxLevelPixels];
   __shared__ float red_sum[4], red_max[4];
   const int img = blockIdx.x, l = blockIdx.y;
   const int h = lv.h[l], w = lv.w[l], P = h * w;
   const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  const T* m = masks ? masks + (long)img * H * W : nullptr;
+  // resized mask value of level pixel p (recomputed, not stored: any image
+  // size works and the kernel needs no per-level LDS array)
+  auto weight = [&](int p) -> float {
+    if (m == nullptr) return 1.f;  // encoders.py:292-293: no masks == all ones
+    const int oy = p / w, ox = p - oy * w;
+    // ATen upsample_bilinear2d, align_corners=false
+    float fy = ((float)oy + 0.5f) * sy - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = ((float)ox + 0.5f) * sx - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const float v00 = (float)m[y0 * W + x0], v01 = (float)m[y0 * W + x1];
+    const float v10 = (float)m[y1 * W + x0], v11 = (float)m[y1 * W + x1];
+    return ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  };
   float lsum = 0.f, lmax = 0.f;
   for (int p = threadIdx.x; p < P; p += 256) {
-    float v;
-    if (masks == nullptr) {
-      v = 1.f;  // encoders.py:292-293: no masks == all ones
-    } else {
-      const T* m = masks + (long)img * H * W;
-      const int oy = p / w, ox = p - oy * w;
-      // ATen upsample_bilinear2d, align_corners=false
-      float fy = ((float)oy + 0.5f) * sy - 0.5f; fy = fy < 0.f ? 0.f : fy;
-      float fx = ((float)ox + 0.5f) * sx - 0.5f; fx = fx < 0.f ? 0.f : fx;
-      const int y0 = (int)fy, x0 = (int)fx;
-      const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-      const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-      const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-      const float v00 = (float)m[y0 * W + x0], v01 = (float)m[y0 * W + x1];
-      const float v10 = (float)m[y1 * W + x0], v11 = (float)m[y1 * W + x1];
-      v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-    }
-    wts[p] = v;
+    const float v = weight(p);
     lsum += v;
     lmax = fmaxf(lmax, fabsf(v));
   }
@@ -534,7 +532,7 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
     int count = 0;
     for (int p0 = 0; p0 < P; p0 += 64) {
       const int p = p0 + threadIdx.x;
-      float v = p < P ? wts[p] : 0.f;
+      float v = p < P ? weight(p) : 0.f;
       if (valid) v = v / total;
       const bool nz = (p < P) && (v != 0.f);
       const unsigned long long mask = __ballot(nz);
@@ -730,9 +728,6 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
                 "encode: workspace too small (%zu needed, %zu given)", ws.off,
                 ws.size);
-  MILAN_REQUIRE(pl.lv.h[0] * pl.lv.w[0] <= kMaxLevelPixels, MILAN_ERR_SHAPE,
-                "encode: image %dx%d too large for the mask pyramid kernel", H,
-                W);
   const int wd = c->d.trunk_width;
   const int F = c->d.feature_size;
 
@@ -1032,9 +1027,7 @@ static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
   MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
                 "encode: workspace too small (%zu needed, %zu given)", ws.off,
                 ws.size);
-  MILAN_REQUIRE(pl.hq[1] >= 1 && pl.wq[1] >= 1 &&
-                    pl.lv.h[0] * pl.lv.w[0] <= kMaxLevelPixels,
-                MILAN_ERR_SHAPE, "encode: image %dx%d unsupported by the alexnet "
+  MILAN_REQUIRE(pl.hq[1] >= 1 && pl.wq[1] >= 1, MILAN_ERR_SHAPE, "encode: image %dx%d unsupported by the alexnet "
                 "pyramid", H, W);
   const int F = c->d.feature_size;
   if (masks == nullptr || mask_dtype == MILAN_DTYPE_U8)

@@ -130,6 +130,23 @@ def test_encoder_no_mask_equals_all_ones(dev, golden_meta):
     ctx.close()
 
 
+@pytest.mark.parametrize('hw', [(300, 260), (256, 256), (37, 450)])
+def test_encoder_large_and_oblong_images(dev, golden_meta, hw):
+    """The reference takes any image size (the pyramid follows the trunk's
+    strides); nothing here may assume 224x224."""
+    h, w = hw
+    m = golden_meta['g1_slim224']
+    ctx, sd = _encoder_ctx(m, dev)
+    g = torch.Generator().manual_seed(h + w)
+    images = torch.randint(0, 256, (2, 3, h, w), dtype=torch.uint8, generator=g)
+    masks = (torch.rand(2, 1, h, w, generator=g) > 0.5).to(torch.uint8)
+    want = O.encode(O.byte_to_float(images)[None], masks[None].float(), sd)[0]
+    for precision in ('f32', 'split_f16'):
+        ctx.set_precision(precision)
+        close(ctx.encode(images, masks), want, rtol=2e-3, atol=2e-4)
+    ctx.close()
+
+
 # --------------------------------------------------------------------------
 # decoder vs goldens / oracle
 # --------------------------------------------------------------------------
