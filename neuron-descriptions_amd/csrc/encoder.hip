@@ -621,15 +621,27 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   long off = 0;
   for (int l = 0; l < 5; ++l) { lv.off[l] = off; off += (long)lv.h[l] * lv.w[l]; }
   lv.per_image = off;
-  const size_t p0 = (size_t)n * pl->hp * pl->wp;  // pixels at layer1 resolution
-  // NHWC4 fp32, or (W+2)/2 pixel-pair groups of 8 slots per row (split stem)
+  // Per-image extents of the activation buffers: the largest tensor each one
+  // ever holds.  At 224x224 that is always the layer1 tensor, but once an image
+  // is so small that the spatial size bottoms out at 1x1 the channel growth of
+  // the later stages wins.
+  const int exp = c->d.trunk_kind == MILAN_TRUNK_BASIC ? 1 : 4;
+  size_t x_sz = (size_t)pl->hp * pl->wp * wd, t1_sz = 0, t2_sz = 0;
+  for (int li = 0; li < 4; ++li) {
+    const size_t planes = (size_t)wd << li;
+    const size_t in_px = (size_t)lv.h[li == 0 ? 1 : li] * lv.w[li == 0 ? 1 : li];
+    const size_t out_px = (size_t)lv.h[li + 1] * lv.w[li + 1];
+    x_sz = x_sz > out_px * planes * exp ? x_sz : out_px * planes * exp;
+    t1_sz = t1_sz > in_px * planes ? t1_sz : in_px * planes;   // c1 output
+    t2_sz = t2_sz > out_px * planes ? t2_sz : out_px * planes; // c2 output
+  }
   pl->in4 = a.get<float>((size_t)n * H * (W + 2) * 4);
   pl->raw = a.get<float>((size_t)n * pl->h1 * pl->w1 * wd);
-  pl->x0 = a.get<float>(p0 * wd * 4);
-  pl->x1 = a.get<float>(p0 * wd * 4);
-  pl->ds = a.get<float>(p0 * wd * 4);
-  pl->t1 = a.get<float>(p0 * wd * 2);
-  pl->t2 = a.get<float>(p0 * wd);
+  pl->x0 = a.get<float>((size_t)n * x_sz);
+  pl->x1 = a.get<float>((size_t)n * x_sz);
+  pl->ds = a.get<float>((size_t)n * x_sz);
+  pl->t1 = a.get<float>((size_t)n * t1_sz);
+  pl->t2 = a.get<float>((size_t)n * t2_sz);
   pl->list_idx = a.get<int>((size_t)n * lv.per_image);
   pl->list_w = a.get<float>((size_t)n * lv.per_image);
   pl->list_n = a.get<int>((size_t)n * 5);
@@ -718,8 +730,8 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                              int W, float* features, Arena& ws, hipStream_t s) {
   MILAN_REQUIRE(c->stem.w != nullptr, MILAN_ERR_STATE,
                 "encoder weights were not uploaded");
-  MILAN_REQUIRE(n > 0 && H >= 32 && W >= 32, MILAN_ERR_SHAPE,
-                "encode: need n>0 and H,W>=32 (got n=%d H=%d W=%d)", n, H, W);
+  MILAN_REQUIRE(n > 0 && H >= 1 && W >= 1, MILAN_ERR_SHAPE,
+                "encode: need n>0 and H,W>=1 (got n=%d H=%d W=%d)", n, H, W);
   if (c->d.trunk_kind == MILAN_TRUNK_ALEXNET)
     return alexnet_run_batch(c, images, image_dtype, masks, mask_dtype, n, H, W,
                              features, ws, s);

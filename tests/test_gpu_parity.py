@@ -130,7 +130,8 @@ def test_encoder_no_mask_equals_all_ones(dev, golden_meta):
     ctx.close()
 
 
-@pytest.mark.parametrize('hw', [(300, 260), (256, 256), (37, 450)])
+@pytest.mark.parametrize('hw', [(300, 260), (256, 256), (37, 450), (16, 16),
+                                (9, 13), (1, 1)])
 def test_encoder_large_and_oblong_images(dev, golden_meta, hw):
     """The reference takes any image size (the pyramid follows the trunk's
     strides); nothing here may assume 224x224."""
