@@ -92,3 +92,62 @@ def test_fuzz_encode_and_decode(seed):
         t, s, _ = O.rerank(want_t, want_s, sd, nv, nv + 1, p['temperature'])
         close(got_b['scores'], s, 1e-4, 3e-3)
     ctx.close()
+
+
+def draw_decoder(seed):
+    r = random.Random(seed)
+    nv = r.choice([5, 9, 33, 100, 257, 1023])
+    return dict(
+        nv=nv, feat=r.choice([64, 72, 244, 488]),
+        hidden=r.choice([4, 20, 36, 64, 100]), emb=r.choice([4, 12, 28, 32]),
+        k=r.randint(1, 17), n=r.randint(1, 9), length=r.randint(1, 21),
+        beam=r.randint(1, min(nv + 4, 24)), mi=r.random() < 0.5,
+        temperature=r.choice([0.05, 0.2, 1.0]),
+        group=r.choice([0, 1, 2, 3]),
+        precision=r.choice(['f32', 'split_f16']))
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_fuzz_decoder_only(seed):
+    """Decoder / LM geometries far from the pretrained one (hidden sizes that
+    are not multiples of 32, k > 15, long sequences, beam == |V|, ragged
+    allennlp groups), features handed in directly."""
+    dev = hip.require_device('cuda')
+    p = draw_decoder(5000 + seed)
+    nv = p['nv']
+    sd = synthetic.decoder_state_dict(nv + 4, feature_size=p['feat'],
+                                      hidden_size=p['hidden'],
+                                      embedding_size=p['emb'], lm=True,
+                                      lm_hidden_size=p['hidden'],
+                                      lm_embedding_size=p['emb'], seed=seed)
+    ctx = hip.Context(hip.make_dims(sd, nv), sd, dev)
+    ctx.set_precision(p['precision'])
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.rand(p['n'], p['k'], p['feat'], generator=g)
+    length, beam = p['length'], p['beam']
+
+    # teacher forcing on random targets: every log-prob the decoder can emit
+    targets = torch.randint(0, nv + 4, (p['n'], length), generator=g)
+    want_f = O.teacher_forced(feats, sd, nv, targets, mi=p['mi'],
+                              temperature=p['temperature'])
+    got_f = ctx.decode(feats, hip.FORCED, length, 1, p['mi'],
+                       p['temperature'], forced=targets)
+    close(got_f['predictions'], want_f.predictions, 1e-4, 5e-4)
+    close(got_f['scores'], want_f.scores, 1e-4, 5e-3)
+
+    # beam search with allennlp's early exit evaluated per group
+    gs = p['group'] or p['n']
+    strategy = hip.BEAM if p['mi'] else hip.RERANK
+    got = ctx.decode(feats, strategy, length, beam, p['mi'], p['temperature'],
+                     group_size=p['group'])
+    for gi, lo in enumerate(range(0, p['n'], gs)):
+        sl = slice(lo, min(p['n'], lo + gs))
+        want_t, want_s = O.beam_search(feats[sl], sd, nv, nv + 1, length, beam,
+                                       mi=p['mi'],
+                                       temperature=p['temperature'])
+        tp = want_t.shape[2]
+        assert int(got['out_len'][gi]) == tp, (p, gi)
+        part = {'beam_tokens': got['beam_tokens'][sl],
+                'beam_scores': got['beam_scores'][sl]}
+        _check_beams(part, want_t, want_s, tp)
+    ctx.close()
