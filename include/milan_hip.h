@@ -166,6 +166,14 @@ int milan_lm_score(milan_ctx* ctx, const int64_t* seqs, int rows, int L,
                    const int32_t* seq_len, float* out, void* workspace,
                    size_t workspace_bytes, milan_stream stream);
 
+/* LanguageModel.forward(inputs, reduce=False) (src/milan/lms.py:58-88): the
+ * log-probabilities of every next token at every position.  seqs (rows,L)
+ * int64; out (rows,L,V).  Used for custom `masks=` reductions and analysis;
+ * the rerank path uses milan_lm_score, which never materialises this. */
+int milan_lm_logprobs(milan_ctx* ctx, const int64_t* seqs, int rows, int L,
+                      float* out, void* workspace, size_t workspace_bytes,
+                      milan_stream stream);
+
 /* The whole hot path for one batch = Decoder.forward(images, masks, ...)
  * (what Decoder.predict calls per batch, src/milan/decoders.py:857-865):
  * encode then decode.  images (n,k,3,H,W), masks (n,k,1,H,W); other

@@ -350,6 +350,16 @@ int milan_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
   return decoder_lm_score(c, seqs, rows, L, seq_len, out, a, (hipStream_t)stream);
 }
 
+int milan_lm_logprobs(milan_ctx* c, const int64_t* seqs, int rows, int L,
+                      float* out, void* workspace, size_t workspace_bytes,
+                      milan_stream stream) {
+  MILAN_REQUIRE(c && seqs && out, MILAN_ERR_ARG,
+                "milan_lm_logprobs: null argument");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  return decoder_lm_logprobs(c, seqs, rows, L, out, a, (hipStream_t)stream);
+}
+
 int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       const float* weight_oihw, const float* bias, int cout,
                       int kh, int kw, int stride, int pad, int relu,

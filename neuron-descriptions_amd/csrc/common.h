@@ -227,6 +227,8 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
                    float* scores, float* predictions, float* attentions,
                    int64_t* beam_tokens, float* beam_scores, int32_t* out_len,
                    Arena& ws, hipStream_t s);
+int decoder_lm_logprobs(milan_ctx* c, const int64_t* seqs, int rows, int L,
+                        float* out, milan::Arena& ws, hipStream_t s);
 int decoder_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
                      const int32_t* seq_len, float* out, Arena& ws,
                      hipStream_t s);

@@ -1217,6 +1217,41 @@ int decoder_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
   return lm_score_impl(c, seqs, rows, L, seq_len, 1, out, &b, s);
 }
 
+// LanguageModel.forward(inputs, reduce=False): log-probs at every position.
+int decoder_lm_logprobs(milan_ctx* c, const int64_t* seqs, int rows, int L,
+                        float* out, Arena& ws, hipStream_t s) {
+  MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
+  MILAN_REQUIRE(c->d.has_lm && c->lm_out.w, MILAN_ERR_NO_LM,
+                "cannot use MI/rerank decoding without an LM");
+  MILAN_REQUIRE(rows > 0 && L >= 1, MILAN_ERR_SHAPE, "lm_logprobs: empty input");
+  const milan_dims& d = c->d;
+  DecBuf b;
+  dec_plan(c, rows, 1, 1, 1, true, ws, &b);
+  c->scratch = ws.off <= ws.size ? b.scratch : nullptr;
+  c->scratch_floats = b.scratch_floats;
+  MILAN_REQUIRE(ws.off <= ws.size, MILAN_ERR_WORKSPACE,
+                "lm_logprobs: workspace too small (%zu needed)", ws.off);
+  const size_t st_bytes =
+      sizeof(float) * (size_t)b.lm[0].rows * d.lm_hidden_size * d.lm_layers;
+  MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].h, 0, st_bytes, s));
+  MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].c, 0, st_bytes, s));
+  int cur = 0;
+  for (int t = 0; t < L; ++t) {
+    hipLaunchKernelGGL(gather_col_kernel, dim3(nblk(rows)), dim3(256), 0, s, seqs,
+                       (long)rows, (long)L, t, b.tok);
+    MILAN_TRY(lm_step(c, b.tok, rows, b.lm[cur], b.lm[cur ^ 1], b.lm_emb,
+                      b.lm_gates, b.lm_logits, s));
+    // log-softmax of position t into out[:, t, :]
+    MILAN_TRY(launch_row_select(b.lm_logits, nullptr, 0.f, rows, d.vocab_size, 0,
+                                nullptr, 0, nullptr, nullptr,
+                                out + (long)t * d.vocab_size,
+                                (long)L * d.vocab_size, s));
+    cur ^= 1;
+  }
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int decoder_decode(milan_ctx* c, const float* features, int n, int k,
                    int strategy, int length, int beam, int mi, float temperature,
                    int group_size, int64_t* tokens, float* scores,

@@ -85,6 +85,7 @@ SIGNATURES = {
         _SZ, _P
     ]),
     'milan_lm_score': (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    'milan_lm_logprobs': (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     'milan_describe': (_I, [
         _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P,
         _P, _P, _P, _P, _P, _P, _SZ, _P
@@ -456,6 +457,21 @@ class Context:
                 self.lib.milan_lm_score(self._h, seqs.data_ptr(), rows, length,
                                         None, out.data_ptr(), ws.data_ptr(),
                                         ws.numel(), _stream(self.device)))
+        return out
+
+    def lm_logprobs(self, seqs: torch.Tensor) -> torch.Tensor:
+        """(rows, L) token ids -> (rows, L, V) next-token log-probs."""
+        rows, length = seqs.shape
+        seqs = _dev(seqs, self.device, torch.long)
+        out = torch.empty(rows, length, self.dims.vocab_size,
+                          device=self.device)
+        ws = self.workspace(rows, 1, 0, 1, 1)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_lm_logprobs(self._h, seqs.data_ptr(), rows,
+                                           length, out.data_ptr(),
+                                           ws.data_ptr(), ws.numel(),
+                                           _stream(self.device)))
         return out
 
     def describe(self,

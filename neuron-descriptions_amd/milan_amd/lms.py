@@ -47,16 +47,28 @@ class LanguageModel(nn.Module):
                 inputs: torch.Tensor,
                 reduce: bool = False,
                 masks: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Sequence log-probabilities (reference lms.py:58-101, reduce=True)."""
-        if not reduce or masks is not None:
-            raise NotImplementedError(
-                'only forward(inputs, reduce=True) with the default stop mask '
-                'is on the inference path (src/milan/decoders.py:504)')
+        """Log-probabilities under the LM (reference lms.py:58-101).
+
+        `reduce=False`: (batch, length, vocab) next-token log-probs at every
+        position.  `reduce=True`: (batch,) sequence log-probs, the first token
+        taken as given; `masks` (batch, length-1) weights the token terms, by
+        default everything after the first stop token is dropped -- with the
+        reference's off-by-one: the term predicting the token AFTER the stop
+        still counts (lms.py:93-95).
+        """
         if self._owner is None:
             raise hip.HipUnavailableError(
                 'LanguageModel scores through its Decoder\'s HIP context; '
                 'attach it to a milan_amd.Decoder first')
-        return self._owner()._context().lm_score(inputs)
+        ctx = self._owner()._context()
+        if reduce and masks is None:
+            return ctx.lm_score(inputs)  # fused: never materialises (B,L,V)
+        lps = ctx.lm_logprobs(inputs)
+        if not reduce:
+            return lps
+        targets = inputs[:, 1:].to(lps.device)
+        picked = lps[:, :-1].gather(2, targets.unsqueeze(-1)).squeeze(-1)
+        return picked.mul(masks.to(lps.device)).sum(dim=-1)
 
     def properties(self) -> Mapping[str, Any]:
         return {

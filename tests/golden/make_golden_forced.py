@@ -14,6 +14,8 @@ make_golden.py) and records, for seeded synthetic weights:
       of option combinations: expected id tuples.
   G10 `Decoder.score(captions, features)` (decoders.py:636-711) with a
       whitespace tokenizer standing in for spaCy on both sides: totals.
+  G12 `LanguageModel.forward` (lms.py:58-101) with reduce=False, reduce=True
+      and reduce=True + caller masks.
 
 Outputs: reference_goldens_forced.pt / .json (data only).
 """
@@ -140,6 +142,20 @@ def main():
                                          temperature=0.3).clone()
         out['g10_scores_broadcast'] = dec.score(captions, feats[:1],
                                                 mi=False).clone()
+
+    # ---- G12: LanguageModel.forward beyond the rerank call ---------------------
+    sg = torch.Generator().manual_seed(72)
+    seqs = torch.randint(0, len(indexer), (5, 7), generator=sg)
+    seqs[:, 0] = indexer.start_index
+    seqs[1, 3] = indexer.stop_index
+    seqs[3, 1] = indexer.stop_index
+    masks = torch.randint(0, 2, (5, 6), generator=sg)
+    out['g12_seqs'] = seqs
+    out['g12_masks'] = masks
+    with torch.no_grad():
+        out['g12_lps'] = lm(seqs).clone()                       # reduce=False
+        out['g12_reduced'] = lm(seqs, reduce=True).clone()      # default mask
+        out['g12_masked'] = lm(seqs, reduce=True, masks=masks).clone()
 
     torch.save(out, HERE / 'reference_goldens_forced.pt')
     with open(HERE / 'reference_goldens_forced.json', 'w') as f:
