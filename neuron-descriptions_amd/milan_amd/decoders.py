@@ -263,13 +263,14 @@ class Decoder(nn.Module):
             if strategy.numel() and (int(strategy.min()) < 0 or
                                      int(strategy.max()) >= self.vocab_size):
                 raise IndexError('index out of range in self')  # nn.Embedding
-        if isinstance(strategy, str) and strategy == STRATEGY_SAMPLE:
-            raise NotImplementedError(
-                "strategy='sample' is outside the MI355X inference path")
         if self.training:
             raise NotImplementedError(
                 'training-mode forward (dropout active) is not built; call '
                 '.eval() -- milan.pretrained() returns eval-mode models')
+
+        if isinstance(strategy, str) and strategy == STRATEGY_SAMPLE:
+            return self._sample(images_or_features, masks, encode, length, mi,
+                                temperature)
 
         ctx = self._context()
         forced = None
@@ -318,6 +319,43 @@ class Decoder(nn.Module):
             beam_scores=beam_scores,
             beam_tokens=beam_tokens,
         )
+
+    def _sample(self, images_or_features, masks, encode, length, mi,
+                temperature) -> DecoderOutput:
+        """`strategy='sample'` (reference :448-453): one token per row drawn
+        from exp(log-probs) with torch's global generator, row by row like the
+        reference, so a seeded run consumes the RNG in the same order.  The
+        steps run through `milan_step`; only the draw itself is torch's."""
+        features = (self.encode(images_or_features, masks=masks)
+                    if encode else images_or_features)
+        features = features.to(self.device)
+        batch_size = len(features)
+        state = self.init_state(features, lm=mi)
+        currents = torch.full((batch_size,), self.indexer.start_index,
+                              dtype=torch.long, device=self.device)
+        tokens = currents.new_zeros(batch_size, length)
+        scores = features.new_zeros(batch_size)
+        predictions = features.new_zeros(batch_size, length, self.vocab_size)
+        attentions = features.new_zeros(batch_size, length, features.shape[1])
+        rows = torch.arange(batch_size, device=self.device)
+        for time in range(length):
+            step = self.step(features, currents, state,
+                             temperature=temperature)
+            currents = currents.clone()
+            for row, logprobs in enumerate(step.predictions):
+                probs = torch.exp(logprobs)
+                currents[row] = torch.distributions.Categorical(
+                    probs=probs).sample()
+            predictions[:, time] = step.predictions
+            attentions[:, time] = step.attentions
+            tokens[:, time] = currents
+            state = step.state
+            scores = scores + step.predictions[rows, currents]
+        return DecoderOutput(
+            captions=self.indexer.reconstruct(tokens.tolist()),
+            scores=scores, tokens=tokens, predictions=predictions,
+            attentions=attentions, beam_captions=None, beam_scores=None,
+            beam_tokens=None)
 
     def encode(self,
                images: torch.Tensor,

@@ -188,3 +188,40 @@ def test_precision_switch_gives_same_captions(model):
         dec.precision = 'bf16'
         dec(images, masks)
     dec.precision = 'f32'
+
+
+def test_sample_strategy(model):
+    """strategy='sample' (reference decoders.py:448-453): seeded runs repeat,
+    the draw order is row by row per step (what a seeded reference run on the
+    same device consumes), scores are the sampled tokens' log-probs."""
+    dec, sd = model
+    g = torch.Generator().manual_seed(5)
+    feats = torch.rand(3, K, dec.feature_size, generator=g).to('cuda')
+    torch.manual_seed(123)
+    a = dec(feats, strategy='sample', mi=False, length=6)
+    torch.manual_seed(123)
+    b = dec(feats, strategy='sample', mi=False, length=6)
+    assert torch.equal(a.tokens, b.tokens) and torch.equal(a.scores, b.scores)
+    assert a.tokens.shape == (3, 6) and a.predictions.shape == (3, 6, NV + 4)
+    assert a.attentions.shape == (3, 6, K) and a.beam_tokens is None
+    assert int(a.tokens.min()) >= 0 and int(a.tokens.max()) < NV + 4
+    picked = a.predictions.gather(2, a.tokens.unsqueeze(-1)).squeeze(-1)
+    torch.testing.assert_close(a.scores, picked.sum(1), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(a.predictions.exp().sum(-1),
+                               torch.ones(3, 6, device='cuda'), rtol=1e-4,
+                               atol=1e-4)
+    # the same loop written out against the step API draws the same tokens
+    torch.manual_seed(123)
+    state = dec.init_state(feats, lm=False)
+    cur = torch.full((3,), NV, dtype=torch.long, device='cuda')
+    for t in range(6):
+        step = dec.step(feats, cur, state)
+        cur = torch.stack([
+            torch.distributions.Categorical(probs=p.exp()).sample()
+            for p in step.predictions
+        ])
+        assert torch.equal(cur, a.tokens[:, t])
+        state = step.state
+    torch.manual_seed(321)
+    c = dec(feats, strategy='sample', mi=False, length=6)
+    assert not torch.equal(a.tokens, c.tokens)
