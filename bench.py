@@ -265,7 +265,7 @@ def main():
         'host_reconstruct_ms': reconstruct_ms,
     }
     # HBM bytes per launch of the dominant kernel: PMC counters need their own
-    # rocprofv3 passes (scratch/pmc_traffic.sh), so the figure is read from the
+    # rocprofv3 passes (tools/pmc_traffic.sh), so the figure is read from the
     # committed summary of those passes, not collected live.
     traffic_bytes, traffic_note = None, 'not collected (PMC needs separate rocprofv3 passes)'
     tpath = pathlib.Path(__file__).resolve().parent / 'profiles' / 'r1_hbm_traffic.json'
