@@ -117,6 +117,16 @@ int milan_encode(milan_ctx* ctx, const void* images, int image_dtype,
                  int width, float* features, void* workspace,
                  size_t workspace_bytes, milan_stream stream);
 
+/* SpatialConvEncoder.forward (src/milan/encoders.py:158-230, config
+ * 'resnet18'): the image is normalised, THEN multiplied by its mask (NULL =
+ * ones), run through the ResNet trunk, and the last stage's output is returned
+ * position-major: out (n_images, h4*w4, C4) = layer4.permute(0,2,3,1), i.e.
+ * (n, 49, 512) for 224x224 / resnet18.  ResNet trunks only. */
+int milan_encode_spatial(milan_ctx* ctx, const void* images, int image_dtype,
+                         const void* masks, int mask_dtype, int n_images,
+                         int height, int width, float* out, void* workspace,
+                         size_t workspace_bytes, milan_stream stream);
+
 /* Decoder.init_state (src/milan/decoders.py:548-574).
  * features (n,k,F) -> h,c (n,hidden). */
 int milan_init_state(milan_ctx* ctx, const float* features, int n, int k,

@@ -283,6 +283,22 @@ int milan_encode(milan_ctx* c, const void* images, int image_dtype,
                      width, features, a, (hipStream_t)stream);
 }
 
+int milan_encode_spatial(milan_ctx* c, const void* images, int image_dtype,
+                         const void* masks, int mask_dtype, int n_images,
+                         int height, int width, float* out, void* workspace,
+                         size_t workspace_bytes, milan_stream stream) {
+  MILAN_REQUIRE(c && images && out, MILAN_ERR_ARG,
+                "milan_encode_spatial: null argument");
+  MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
+  MILAN_REQUIRE((image_dtype == MILAN_DTYPE_U8 || image_dtype == MILAN_DTYPE_F32) &&
+                    (mask_dtype == MILAN_DTYPE_U8 || mask_dtype == MILAN_DTYPE_F32),
+                MILAN_ERR_ARG, "bad dtype");
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  return encoder_run_spatial(c, images, image_dtype, masks, mask_dtype, n_images,
+                             height, width, out, a, (hipStream_t)stream);
+}
+
 int milan_init_state(milan_ctx* c, const float* features, int n, int k, float* h,
                      float* cc, void* workspace, size_t workspace_bytes,
                      milan_stream stream) {

@@ -208,6 +208,9 @@ int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
                     float* wp, hipStream_t s);
 int encoder_finalize(milan_ctx* c, hipStream_t s);
 size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W);
+int encoder_run_spatial(milan_ctx* c, const void* images, int image_dtype,
+                        const void* masks, int mask_dtype, int n, int H, int W,
+                        float* out, milan::Arena& ws, hipStream_t s);
 int encoder_run(milan_ctx* c, const void* images, int image_dtype,
                 const void* masks, int mask_dtype, int n_images, int H, int W,
                 float* features, Arena& ws, hipStream_t s);

@@ -302,7 +302,9 @@ template <typename T>
 __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
                                   int hw, float m0, float m1, float m2,
                                   float s0, float s1, float s2,
-                                  float4* __restrict__ out) {
+                                  float4* __restrict__ out,
+                                  const void* __restrict__ mul = nullptr,
+                                  int mul_u8 = 1) {
   // the byte->float product is rounded on its own, as in the reference: no
   // contraction into the mean subtraction
 #pragma clang fp contract(off)
@@ -319,7 +321,12 @@ __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
     } else {
       v0 = base[0]; v1 = base[hw]; v2 = base[2 * (long)hw];
     }
-    out[p] = make_float4((v0 - m0) / s0, (v1 - m1) / s1, (v2 - m2) / s2, 0.f);
+    // SpatialConvEncoder (encoders.py:204-208): normalise, THEN mask
+    const float k = mul == nullptr ? 1.f
+                    : mul_u8     ? (float)((const uint8_t*)mul)[p]
+                                 : ((const float*)mul)[p];
+    out[p] = make_float4(((v0 - m0) / s0) * k, ((v1 - m1) / s1) * k,
+                         ((v2 - m2) / s2) * k, 0.f);
   }
 }
 
@@ -375,6 +382,26 @@ __device__ inline void enc_split8(const float* v, f32x4_t* hi_out,
   *lo_out = __builtin_bit_cast(f32x4_t, l);
 }
 
+// split-format groups [hi x8 | lo x8] -> 8 fp32 values each
+__global__ void split_to_f32_kernel(const float* __restrict__ x, long groups,
+                                    float* __restrict__ y) {
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < groups;
+       q += (long)gridDim.x * blockDim.x) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(x + q * 8);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(x + q * 8 + 4);
+    const f16x8_t hh = __builtin_bit_cast(f16x8_t, a);
+    const f16x8_t ll = __builtin_bit_cast(f16x8_t, b);
+    f32x4_t o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = (float)hh[e] + (float)ll[e];
+      o1[e] = (float)hh[4 + e] + (float)ll[4 + e];
+    }
+    *reinterpret_cast<f32x4_t*>(y + q * 8) = o0;
+    *reinterpret_cast<f32x4_t*>(y + q * 8 + 4) = o1;
+  }
+}
+
 // NCHW u8/f32 -> normalised pixel-pair groups in split-f16 format:
 // out[img][y][p] = split8(RGB0 of x=2p-1, RGB0 of x=2p), p in [0, G), zeros
 // outside the image (see pack_stem_pairs_kernel).
@@ -382,7 +409,9 @@ template <typename T>
 __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups,
                                         int H, int W, int G, float m0, float m1,
                                         float m2, float s0, float s1, float s2,
-                                        float* __restrict__ out) {
+                                        float* __restrict__ out,
+                                        const void* __restrict__ mul = nullptr,
+                                        int mul_u8 = 1) {
 #pragma clang fp contract(off)  // see preprocess_kernel
   const float inv255 = (float)(1.0 / 255.0);
   const long hw = (long)H * W;
@@ -406,7 +435,12 @@ __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups
         } else {
           a = base[x]; b = base[hw + x]; cc = base[2 * hw + x];
         }
-        a = (a - m0) / s0; b = (b - m1) / s1; cc = (cc - m2) / s2;
+        const long mp = n * hw + (long)y * W + x;
+        const float k = mul == nullptr ? 1.f
+                        : mul_u8     ? (float)((const uint8_t*)mul)[mp]
+                                     : ((const float*)mul)[mp];
+        a = ((a - m0) / s0) * k; b = ((b - m1) / s1) * k;
+        cc = ((cc - m2) / s2) * k;
       }
       v[4 * h] = a; v[4 * h + 1] = b; v[4 * h + 2] = cc; v[4 * h + 3] = 0.f;
     }
@@ -702,7 +736,8 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
 
 static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                              const void* masks, int mask_dtype, int n, int H,
-                             int W, float* features, Arena& ws, hipStream_t s);
+                             int W, float* features, Arena& ws, hipStream_t s,
+                             float* spatial_out = nullptr);
 static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
                              const void* masks, int mask_dtype, int n, int H,
                              int W, float* features, Arena& ws, hipStream_t s);
@@ -725,9 +760,42 @@ int encoder_run(milan_ctx* c, const void* images, int image_dtype,
   return 0;
 }
 
+// spatial_out != nullptr: SpatialConvEncoder mode (encoders.py:158-230) -- the
+// image is normalised and THEN multiplied by its mask, no pyramid pooling, and
+// the last stage's NHWC output (n, h4*w4, C4) is the result.
+int encoder_run_spatial(milan_ctx* c, const void* images, int image_dtype,
+                        const void* masks, int mask_dtype, int n, int H, int W,
+                        float* out, Arena& ws, hipStream_t s) {
+  MILAN_REQUIRE(c->d.trunk_kind != MILAN_TRUNK_ALEXNET, MILAN_ERR_ARG,
+                "spatial encoding needs a ResNet trunk");
+  Arena dry; dry.dry = true;
+  EncPlan pl;
+  plan(c, 1, H, W, dry, &pl);
+  const int C = (c->d.trunk_kind == MILAN_TRUNK_BASIC ? c->d.trunk_width
+                                                      : c->d.trunk_width * 4) << 3;
+  const size_t per_image = (size_t)pl.lv.h[4] * pl.lv.w[4] * C;
+  const int sub = encoder_sub_batch();
+  const size_t isz = image_dtype == MILAN_DTYPE_U8 ? 1 : 4;
+  const size_t msz = mask_dtype == MILAN_DTYPE_U8 ? 1 : 4;
+  for (int lo = 0; lo < n; lo += sub) {
+    const int cnt = n - lo < sub ? n - lo : sub;
+    Arena a = ws;
+    const char* im = (const char*)images + (size_t)lo * 3 * H * W * isz;
+    const char* mk = masks ? (const char*)masks + (size_t)lo * H * W * msz : nullptr;
+    MILAN_TRY(encoder_run_batch(c, im, image_dtype, mk, mask_dtype, cnt, H, W,
+                                nullptr, a, s, out + lo * per_image));
+    if (a.off > ws.off) ws.off = a.off > ws.size ? ws.size : ws.off;
+  }
+  return 0;
+}
+
 static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                              const void* masks, int mask_dtype, int n, int H,
-                             int W, float* features, Arena& ws, hipStream_t s) {
+                             int W, float* features, Arena& ws, hipStream_t s,
+                             float* spatial_out) {
+  const bool spatial = spatial_out != nullptr;
+  MILAN_REQUIRE(!spatial || c->d.trunk_kind != MILAN_TRUNK_ALEXNET, MILAN_ERR_ARG,
+                "spatial encoding needs a ResNet trunk");
   MILAN_REQUIRE(c->stem.w != nullptr, MILAN_ERR_STATE,
                 "encoder weights were not uploaded");
   MILAN_REQUIRE(n > 0 && H >= 1 && W >= 1, MILAN_ERR_SHAPE,
@@ -744,7 +812,9 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   const int F = c->d.feature_size;
 
   // 1. masks -> per-level normalised sparse weight lists
-  if (masks == nullptr || mask_dtype == MILAN_DTYPE_U8)
+  if (spatial) {
+    // no pooling
+  } else if (masks == nullptr || mask_dtype == MILAN_DTYPE_U8)
     hipLaunchKernelGGL(mask_pyramid_kernel<uint8_t>, dim3(n, 5), dim3(256), 0, s,
                        (const uint8_t*)masks, H, W, pl.lv, pl.list_idx,
                        pl.list_w, pl.list_n);
@@ -769,26 +839,29 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     const int blocks = (int)((np + 255) / 256 < 8192 ? (np + 255) / 256 : 8192);
     const float m0 = c->mean[0], m1 = c->mean[1], m2 = c->mean[2];
     const float s0 = c->stdv[0], s1 = c->stdv[1], s2 = c->stdv[2];
+    const void* mul = spatial ? masks : nullptr;  // spatial mode: x * mask
+    const int mul_u8 = mask_dtype == MILAN_DTYPE_U8;
     if (pair_stem && image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_pairs_kernel<uint8_t>, dim3(blocks),
                          dim3(256), 0, s, (const uint8_t*)images, np, H, W, G,
-                         m0, m1, m2, s0, s1, s2, pl.in4);
+                         m0, m1, m2, s0, s1, s2, pl.in4, mul, mul_u8);
     else if (pair_stem)
       hipLaunchKernelGGL(preprocess_pairs_kernel<float>, dim3(blocks), dim3(256),
                          0, s, (const float*)images, np, H, W, G, m0, m1, m2, s0,
-                         s1, s2, pl.in4);
+                         s1, s2, pl.in4, mul, mul_u8);
     else if (image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
                          s, (const uint8_t*)images, np, H * W, m0, m1, m2, s0, s1,
-                         s2, (float4*)pl.in4);
+                         s2, (float4*)pl.in4, mul, mul_u8);
     else
       hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
                          (const float*)images, np, H * W, m0, m1, m2, s0, s1, s2,
-                         (float4*)pl.in4);
+                         (float4*)pl.in4, mul, mul_u8);
     MILAN_CHECK_HIP(hipGetLastError());
   }
 
   auto pool = [&](const float* tap, int level, int C, int col_off) -> int {
+    if (spatial) return 0;
     const int P = pl.lv.h[level] * pl.lv.w[level];
     if (split && level > 0)
       hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
@@ -902,6 +975,21 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                   "internal: stage %d geometry mismatch", li + 1);
     MILAN_TRY(pool(x, li + 1, C, col));
     col += C;
+  }
+  if (spatial) {
+    // layer4 output, NHWC == the reference's permute(0, 2, 3, 1): (n, h*w, C)
+    const int C = (c->d.trunk_kind == MILAN_TRUNK_BASIC ? wd : wd * 4) << 3;
+    const long rows = (long)n * h * w;
+    if (split) {
+      const long total = rows * (C / 8);
+      const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+      hipLaunchKernelGGL(split_to_f32_kernel, dim3(blocks), dim3(256), 0, s, x,
+                         total, spatial_out);
+      MILAN_CHECK_HIP(hipGetLastError());
+    } else {
+      MILAN_CHECK_HIP(hipMemcpyAsync(spatial_out, x, sizeof(float) * rows * C,
+                                     hipMemcpyDeviceToDevice, s));
+    }
   }
   return 0;
 }

@@ -9,7 +9,8 @@ its arithmetic runs in libmilan_hip (`milan_encode`).  All four configs of the
 reference's table (encoders.py:326-351) are built: 'alexnet', 'resnet18',
 'resnet50', 'resnet101' (plus the same-shaped resnet34 / resnet152); unknown
 names raise ValueError like the reference (encoders.py:265-267).
-`SpatialConvEncoder` is out of scope.
+`SpatialConvEncoder` (encoders.py:158-234, config 'resnet18') runs on the same
+trunk kernels through `milan_encode_spatial`.
 """
 from typing import Any, Mapping, Optional, Tuple, Type, Union
 
@@ -80,26 +81,16 @@ class Encoder(nn.Module):
         return data.TensorDataset(torch.cat(mapped))
 
 
-class PyramidConvEncoder(Encoder):
-    """Masked multi-resolution ResNet features (reference encoders.py:243).
+class _HipTrunkEncoder(Encoder):
+    """Shared plumbing of the encoders whose trunk runs in libmilan_hip:
+    owns `encoder.model.*` (torchvision key names) + `mean` / `std`, builds a
+    HIP context lazily and rebuilds it when device or weights change."""
 
-    Owns `encoder.model.*` (torchvision key names), `mean`, `std`.  Extra
-    keyword arguments (`pretrained=`, ...) are kept for serialisation only:
-    there is no torchvision download here, weights come from the checkpoint.
-    """
-
-    def __init__(self, config: str = 'resnet50', **kwargs: Any):
-        super().__init__()
-        configs = PyramidConvEncoder.configs()
-        if config not in configs:
-            raise ValueError(f'encoder not supported: {config}')
+    def _init_trunk(self, config: str, kwargs: Mapping[str, Any]) -> None:
         self.config = config
         self.kwargs = dict(kwargs)
         self.kwargs.setdefault('pretrained', True)
         self.width = int(self.kwargs.get('width', 64))
-        self.blocks, self.layers = configs[config]
-        self.feature_shape = (synthetic.pyramid_feature_size(config,
-                                                             self.width),)
         self.encoder = params.ParamTree()
         if config == 'alexnet':
             spec = params.alexnet_spec(self.width, 'model.')
@@ -157,6 +148,67 @@ class PyramidConvEncoder(Encoder):
             self._ctx_key = key
         return self._ctx
 
+    def properties(self) -> Mapping[str, Any]:
+        return {'config': self.config, **self.kwargs}
+
+
+class SpatialConvEncoder(_HipTrunkEncoder):
+    """Spatial conv features of the masked image (reference
+    encoders.py:158-230): normalise, multiply by the mask, ResNet-18, and hand
+    out layer4 position-major -- (M, 49, 512) for 224x224 inputs."""
+
+    def __init__(self, config: str = 'resnet18', **kwargs: Any):
+        super().__init__()
+        configs = SpatialConvEncoder.configs()
+        if config not in configs:
+            raise ValueError(f'encoder not supported: {config}')
+        self.blocks, (self.layer,), n_features, feature_size = configs[config]
+        self._init_trunk(config, kwargs)
+        self.feature_shape = (n_features, feature_size * self.width // 64)
+
+    def forward(self,
+                images: torch.Tensor,
+                masks: Optional[torch.Tensor] = None,
+                normalize: bool = True,
+                **_: Any) -> torch.Tensor:
+        if not normalize:
+            raise ValueError('normalize=False is not supported by the HIP '
+                             'encoder (normalisation is fused into the input '
+                             'conversion kernel)')
+        return self._context().encode_spatial(images, masks)
+
+    def map(self, *args: Any, **kwargs: Any) -> data.TensorDataset:
+        """`Encoder.map` with single-image defaults (reference :214-223)."""
+        kwargs.setdefault('mask', False)
+        kwargs.setdefault('image_index', 0)
+        return super().map(*args, **kwargs)
+
+    @staticmethod
+    def configs():
+        """name -> (blocks, layers, n_features, feature_size); reference
+        encoders.py:230-234 (49 positions hold for 224x224 inputs)."""
+        return {'resnet18': (synthetic.RESNET_BLOCKS['resnet18'], ('layer4',),
+                             49, 512)}
+
+
+class PyramidConvEncoder(_HipTrunkEncoder):
+    """Masked multi-resolution ResNet features (reference encoders.py:243).
+
+    Owns `encoder.model.*` (torchvision key names), `mean`, `std`.  Extra
+    keyword arguments (`pretrained=`, ...) are kept for serialisation only:
+    there is no torchvision download here, weights come from the checkpoint.
+    """
+
+    def __init__(self, config: str = 'resnet50', **kwargs: Any):
+        super().__init__()
+        configs = PyramidConvEncoder.configs()
+        if config not in configs:
+            raise ValueError(f'encoder not supported: {config}')
+        self.blocks, self.layers = configs[config]
+        self._init_trunk(config, kwargs)
+        self.feature_shape = (synthetic.pyramid_feature_size(config,
+                                                             self.width),)
+
     def forward(self,
                 images: torch.Tensor,
                 masks: Optional[torch.Tensor] = None,
@@ -172,9 +224,6 @@ class PyramidConvEncoder(Encoder):
                              'encoder (normalisation is fused into the input '
                              'conversion kernel)')
         return self._context().encode(images, masks)
-
-    def properties(self) -> Mapping[str, Any]:
-        return {'config': self.config, **self.kwargs}
 
     @staticmethod
     def configs():
@@ -193,22 +242,23 @@ class PyramidConvEncoder(Encoder):
 
 def parse(key: str) -> Type[Encoder]:
     """Parse the string key into an encoder type (reference :354-359)."""
-    try:
-        return {'PyramidConvEncoder': PyramidConvEncoder}[key]
-    except KeyError:
-        raise KeyError(
-            f'{key}: only PyramidConvEncoder is built for MI355X') from None
+    return {Type.__name__: Type
+            for Type in (SpatialConvEncoder, PyramidConvEncoder)}[key]
 
 
 def key(encoder: Encoder) -> str:
     return type(encoder).__name__
 
 
+KIND_SPATIAL = 'spatial'
 KIND_PYRAMID = 'pyramid'
 
 
 def encoder(kind: str = KIND_PYRAMID, **kwargs: Any) -> Encoder:
-    """Create an encoder (reference :371-391)."""
+    """Create an encoder: 'pyramid', 'spatial' or an exact type name
+    (reference :371-391)."""
+    if kind == KIND_SPATIAL:
+        return SpatialConvEncoder(**kwargs)
     if kind == KIND_PYRAMID:
         return PyramidConvEncoder(**kwargs)
     return parse(kind)(**kwargs)

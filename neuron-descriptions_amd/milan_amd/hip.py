@@ -76,6 +76,7 @@ SIGNATURES = {
     'milan_finalize_weights': (_I, [_P, _P]),
     'milan_workspace_bytes': (_SZ, [_P, _I, _I, _I, _I, _I]),
     'milan_encode': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    'milan_encode_spatial': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     'milan_init_state': (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
     'milan_step':
         (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _SZ,
@@ -300,6 +301,42 @@ class Context:
                                       _ptr(masks), mdt, m, h, w,
                                       out.data_ptr(), ws.data_ptr(),
                                       ws.numel(), _stream(self.device)))
+        return out
+
+    def encode_spatial(self, images: torch.Tensor,
+                       masks: Optional[torch.Tensor]) -> torch.Tensor:
+        """SpatialConvEncoder: (M,3,H,W) [+ (M,1,H,W)] -> (M, h4*w4, C4)."""
+        m, ch, h, w = images.shape
+        if ch != 3:
+            raise ValueError(f'images must have 3 channels, got {ch}')
+        idt = DTYPE_U8 if images.dtype == torch.uint8 else DTYPE_F32
+        images = _dev(images, self.device,
+                      None if idt == DTYPE_U8 else torch.float32)
+        mdt = DTYPE_U8
+        if masks is not None:
+            if masks.shape != (m, 1, h, w):
+                raise ValueError(
+                    f'masks shape {tuple(masks.shape)} != {(m, 1, h, w)}')
+            mdt = DTYPE_U8 if masks.dtype == torch.uint8 else DTYPE_F32
+            masks = _dev(masks, self.device,
+                         None if mdt == DTYPE_U8 else torch.float32)
+
+        def down(x, k, s, p):
+            return (x + 2 * p - k) // s + 1
+
+        h4, w4 = down(h, 7, 2, 3), down(w, 7, 2, 3)
+        for _ in range(4):  # maxpool + the three stride-2 stages
+            h4, w4 = down(h4, 3, 2, 1), down(w4, 3, 2, 1)
+        mult = 8 if self.dims.trunk_kind == TRUNK_BASIC else 32
+        out = torch.empty(m, h4 * w4, mult * self.dims.trunk_width,
+                          dtype=torch.float32, device=self.device)
+        ws = self.workspace(m or 1, 1, max(h, w), 1, 1)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.milan_encode_spatial(self._h, images.data_ptr(), idt,
+                                              _ptr(masks), mdt, m, h, w,
+                                              out.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), _stream(self.device)))
         return out
 
     def init_state(self, features: torch.Tensor):

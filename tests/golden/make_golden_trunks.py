@@ -147,6 +147,30 @@ def main():
     run('alexnet', 16, 100, 4, 23, 'alex_100')
     run('alexnet', 64, 224, 3, 24, 'alex_full')   # real alexnet dims (F=1152)
 
+    # ---- G13: SpatialConvEncoder (encoders.py:158-234) -------------------------
+    def run_spatial(width, size, m, seed, tag, with_masks):
+        sd = synthetic.resnet_state_dict('resnet18', seed=seed, width=width)
+        enc = encoders.SpatialConvEncoder(config='resnet18', pretrained=False,
+                                          width=width)
+        enc.encoder.model.load_state_dict(sd, strict=True)
+        enc.eval()
+        images_u8, masks_u8 = synthetic.exemplars(1, k=m, size=size,
+                                                  seed=seed + 10, zero_every=0)
+        images = ren(images_u8.float().view(-1, 3, size, size))
+        masks = masks_u8.float().view(-1, 1, size, size)
+        # the reference hard-codes (49, 512); follow the actual tensor instead
+        h4 = -(-size // 32)
+        enc.feature_shape = (h4 * h4, 8 * width)
+        with torch.no_grad():
+            feats = enc(images, masks if with_masks else None)
+        out[f'g13_{tag}_features'] = feats.clone()
+        meta[f'g13_{tag}'] = dict(width=width, size=size, m=m, weight_seed=seed,
+                                  image_seed=seed + 10, with_masks=with_masks)
+
+    run_spatial(16, 96, 3, 31, 'sp_96', True)
+    run_spatial(16, 96, 3, 31, 'sp_96_nomask', False)
+    run_spatial(64, 224, 2, 32, 'sp_full', True)  # (2, 49, 512)
+
     torch.save(out, HERE / 'reference_goldens_trunks.pt')
     with open(HERE / 'reference_goldens_trunks.json', 'w') as f:
         json.dump(meta, f, indent=1, sort_keys=True)

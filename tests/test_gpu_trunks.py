@@ -86,3 +86,55 @@ def test_dims_reject_inconsistent_trunk(dev):
     dims.trunk_kind = 7
     with pytest.raises(ValueError):
         hip.Context(dims, sd, dev)
+
+
+from tests.test_trunk_goldens import SPATIAL_TAGS, spatial_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize('precision', ['f32', 'split_f16'])
+@pytest.mark.parametrize('tag', SPATIAL_TAGS)
+def test_spatial_encoder_matches_reference_golden(dev, trunk_goldens,
+                                                  trunk_meta, tag, precision):
+    """SpatialConvEncoder (encoders.py:158-234) through milan_encode_spatial:
+    u8 and float inputs, with and without masks."""
+    m = trunk_meta[f'g13_{tag}']
+    sd = synthetic.resnet_state_dict('resnet18', seed=m['weight_seed'],
+                                     width=m['width'],
+                                     prefix='encoder.encoder.model.')
+    ctx = hip.Context(
+        hip.make_dims(sd, 10, blocks=synthetic.RESNET_BLOCKS['resnet18']), sd,
+        dev)
+    ctx.set_precision(precision)
+    images_u8, masks_u8 = spatial_inputs(m)
+    want = trunk_goldens[f'g13_{tag}_features']
+    got = ctx.encode_spatial(images_u8, masks_u8)
+    assert got.shape == want.shape
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    got_f = ctx.encode_spatial(
+        O.byte_to_float(images_u8),
+        None if masks_u8 is None else masks_u8.float())
+    torch.testing.assert_close(got_f.cpu(), want, rtol=2e-3, atol=2e-4)
+    ctx.close()
+
+
+def test_spatial_encoder_module(dev, trunk_goldens, trunk_meta):
+    m = trunk_meta['g13_sp_96']
+    enc = encoders.encoder('spatial', config='resnet18', pretrained=False,
+                           width=m['width'])
+    assert isinstance(enc, encoders.SpatialConvEncoder)
+    assert encoders.parse('SpatialConvEncoder') is encoders.SpatialConvEncoder
+    sd = synthetic.resnet_state_dict('resnet18', seed=m['weight_seed'],
+                                     width=m['width'], prefix='encoder.model.')
+    res = enc.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and set(res.missing_keys) <= {'mean', 'std'}
+    enc.to('cuda')
+    images_u8, masks_u8 = spatial_inputs(m)
+    got = enc(O.byte_to_float(images_u8), masks_u8.float())
+    torch.testing.assert_close(got.cpu(), trunk_goldens['g13_sp_96_features'],
+                               rtol=2e-3, atol=2e-4)
+    with pytest.raises(ValueError, match='encoder not supported'):
+        encoders.SpatialConvEncoder('resnet50')
+    # the 224x224 geometry the reference hard-codes: (49, 512)
+    assert encoders.SpatialConvEncoder('resnet18',
+                                       pretrained=False).feature_shape == (49,
+                                                                           512)

@@ -46,3 +46,28 @@ def test_feature_sizes_match_reference_config_table():
     assert synthetic.pyramid_feature_size('resnet18') == 1024
     assert synthetic.pyramid_feature_size('resnet50') == 3904
     assert synthetic.pyramid_feature_size('resnet101') == 3904
+
+
+SPATIAL_TAGS = ['sp_96', 'sp_96_nomask', 'sp_full']
+
+
+def spatial_inputs(m):
+    images_u8, masks_u8 = synthetic.exemplars(1, k=m['m'], size=m['size'],
+                                              seed=m['image_seed'],
+                                              zero_every=0)
+    return images_u8[0], (masks_u8[0] if m['with_masks'] else None)
+
+
+@pytest.mark.parametrize('tag', SPATIAL_TAGS)
+def test_g13_oracle_spatial_encoder(trunk_goldens, trunk_meta, tag):
+    """SpatialConvEncoder.forward: normalise, THEN mask, layer4 NHWC."""
+    m = trunk_meta[f'g13_{tag}']
+    sd = synthetic.resnet_state_dict('resnet18', seed=m['weight_seed'],
+                                     width=m['width'],
+                                     prefix='encoder.encoder.model.')
+    images_u8, masks_u8 = spatial_inputs(m)
+    got = O.encode_spatial(O.byte_to_float(images_u8),
+                           None if masks_u8 is None else masks_u8.float(), sd)
+    want = trunk_goldens[f'g13_{tag}_features']
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5)
