@@ -138,3 +138,37 @@ def test_spatial_encoder_module(dev, trunk_goldens, trunk_meta):
     assert encoders.SpatialConvEncoder('resnet18',
                                        pretrained=False).feature_shape == (49,
                                                                            512)
+
+
+def test_decoder_over_spatial_encoder(dev):
+    """A Decoder whose encoder is a SpatialConvEncoder: (B,3,H,W) images ->
+    (B, positions, C) features -> captions, against the oracle."""
+    from milan_amd import decoders, lang
+    nv, width, size, n = 30, 16, 96, 3
+    idx = lang.Indexer(lang.Vocab(synthetic.vocab_tokens(nv)), None, True,
+                       True, True, True, 15)
+    enc = encoders.SpatialConvEncoder('resnet18', pretrained=False,
+                                      width=width)
+    dec = decoders.Decoder(idx, enc, None, embedding_size=16, hidden_size=32,
+                           length=6, beam_size=3)
+    assert dec.feature_size == 8 * width
+    sd = synthetic.decoder_state_dict(nv + 4, feature_size=8 * width,
+                                      hidden_size=32, embedding_size=16,
+                                      lm=False, seed=3)
+    trunk = synthetic.resnet_state_dict('resnet18', seed=4, width=width,
+                                        prefix='encoder.encoder.model.')
+    sd.update(trunk)
+    res = dec.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    dec.to('cuda')
+    g = torch.Generator().manual_seed(9)
+    images = torch.rand(n, 3, size, size, generator=g)
+    masks = (torch.rand(n, 1, size, size, generator=g) > 0.4).float()
+    feats = O.encode_spatial(images, masks, trunk)
+    want = O.forward(feats, sd, nv, 'greedy', length=6, mi=False)
+    out = dec(images, masks, strategy='greedy')
+    torch.testing.assert_close(dec.encode(images, masks).cpu(), feats,
+                               rtol=2e-3, atol=2e-4)
+    top2 = want['predictions'].topk(2, dim=-1).values
+    from tests.test_gpu_parity import assert_tokens_match
+    assert_tokens_match(out.tokens, want['tokens'], top2[..., 0] - top2[..., 1])
