@@ -335,3 +335,10 @@ def test_world_size_two_broadcast_and_gather_over_gloo(tmp_path):
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / 'ok0').read_text() == 'True'
     assert (tmp_path / 'ok1').read_text() == 'True'
+
+
+def test_graft_entry_build_runs():
+    """`__graft_entry__.build()` is the driver's "does it build" check."""
+    import __graft_entry__
+    __graft_entry__.build()
+    assert callable(__graft_entry__.smoke)
