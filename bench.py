@@ -103,7 +103,7 @@ def main():
                     help='do not bracket GEMM launches with HIP events')
     ap.add_argument('--pipeline', type=int, default=0,
                     help='1: run the encoder of step i+1 on a second HIP stream '
-                    'while step i decodes (measured +2 % with --no-profile, 2x '
+                    'while step i decodes (measured +2%% with --no-profile, 2x '
                     'slower with per-launch event profiling on); 0: strictly '
                     'serial steps (default)')
     ap.add_argument('--from-host-steps', type=int, default=0,

@@ -342,3 +342,24 @@ def test_graft_entry_build_runs():
     import __graft_entry__
     __graft_entry__.build()
     assert callable(__graft_entry__.smoke)
+
+
+def test_bench_and_script_entry_points_parse():
+    """bench.py / the drop-in script at least import and parse their flags on
+    a CPU-only host (the driver launches them by path)."""
+    import subprocess
+    import sys
+    root = HEADER.parent.parent
+    for path in (root / 'bench.py',
+                 root / 'neuron-descriptions_amd' / 'scripts' /
+                 'compute_milan_descriptions.py'):
+        out = subprocess.run([sys.executable, str(path), '--help'],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+    out = subprocess.run([sys.executable, str(root / 'bench.py'), '--gpus', '1',
+                          '--steps', '1'], capture_output=True, text=True,
+                         timeout=300)
+    # no GPU here: must fail loudly, not fall back to a CPU path
+    assert out.returncode != 0
+    assert 'no CPU fallback' in out.stderr or 'HIP' in out.stderr or \
+        'cuda' in out.stderr.lower()
