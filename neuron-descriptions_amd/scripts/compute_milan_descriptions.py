@@ -1,15 +1,19 @@
-"""Compute MILAN descriptions for a model/dataset pair on MI355X.
+"""Describe every neuron of a model/dataset pair with MILAN on MI355X.
 
-Drop-in for the reference's `scripts/compute_milan_descriptions.py` (same
-positional arguments, flags and CSV output); the only edits are the two
-imports.  With `torchrun --nproc-per-node N` the neurons are sharded over N
-GPUs (weights broadcast from rank 0, descriptions gathered on rank 0).
+Command-line contract of the reference's `scripts/compute_milan_descriptions.py`
+(positional `model dataset`, `--temperature --beam-size --data-dir
+--results-dir --milan --device`, CSV `layer,unit,description` named
+`<model>_<dataset>.csv`), so existing job scripts keep working.  Additions:
+`--milan-path` (there is no downloader here) and multi-GPU sharding -- under
+`torchrun --nproc-per-node N` every rank describes a contiguous block of the
+neurons and rank 0 writes the CSV in the reference's order.
 """
 import argparse
 import csv
 import os
 import pathlib
 import sys
+from typing import List, Sequence, Tuple
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 
@@ -20,58 +24,78 @@ import milan_amd as milan  # noqa: E402
 from milan_amd import datasets as milannotations  # noqa: E402
 from milan_amd import sharding  # noqa: E402
 
-parser = argparse.ArgumentParser(description='compute milan descriptions')
-parser.add_argument('model', help='model architecture (e.g. alexnet)')
-parser.add_argument('dataset', help='dataset model trained on (e.g. imagenet)')
-parser.add_argument('--temperature', type=float, default=.2,
-                    help='pmi temperature (default: .2)')
-parser.add_argument('--beam-size', type=int, default=50,
-                    help='beam size to rerank (default: 50)')
-parser.add_argument('--data-dir', type=pathlib.Path,
-                    help='root dir for datasets (default: $MILAN_DATA_DIR)')
-parser.add_argument('--results-dir', type=pathlib.Path,
-                    help='root dir for final results')
-parser.add_argument('--milan', default='base',
-                    help='milan model to use (default: base)')
-parser.add_argument('--milan-path', type=pathlib.Path,
-                    help='explicit checkpoint path (no network here)')
-parser.add_argument('--device', help='manually set device (default: cuda)')
-args = parser.parse_args()
 
-rank, world, local = sharding.init_from_env()
-device = args.device or f'cuda:{local}'
+def parse_args(argv=None) -> argparse.Namespace:
+    p = argparse.ArgumentParser(description='compute milan descriptions')
+    p.add_argument('model', help='model architecture (e.g. alexnet)')
+    p.add_argument('dataset', help='dataset model trained on (e.g. imagenet)')
+    p.add_argument('--milan', default='base',
+                   help='milan model to use (default: base)')
+    p.add_argument('--milan-path', type=pathlib.Path,
+                   help='explicit checkpoint path (no network here)')
+    p.add_argument('--temperature', type=float, default=.2,
+                   help='pmi temperature (default: .2)')
+    p.add_argument('--beam-size', type=int, default=50,
+                   help='beam size to rerank (default: 50)')
+    p.add_argument('--data-dir', type=pathlib.Path,
+                   help='root dir for datasets (default: $MILAN_DATA_DIR)')
+    p.add_argument('--results-dir', type=pathlib.Path,
+                   help='root dir for final results')
+    p.add_argument('--device', help='manually set device (default: cuda)')
+    return p.parse_args(argv)
 
-key = f'{args.model}/{args.dataset}'
-data_dir = args.data_dir or pathlib.Path(os.environ.get('MILAN_DATA_DIR', 'data'))
-data_root = data_dir / key
-results_dir = args.results_dir or pathlib.Path(
-    os.environ.get('MILAN_RESULTS_DIR', 'results')) / 'descriptions'
 
-decoder = milan.pretrained(args.milan, path=args.milan_path)
-decoder.to(device)
+def env_dir(value, variable: str, default: str) -> pathlib.Path:
+    return value or pathlib.Path(os.environ.get(variable, default))
 
-dataset = milannotations.load(key, path=data_root)
-lo, hi = sharding.partition(len(dataset), world, rank)
-shard = data.Subset(dataset, range(lo, hi)) if world > 1 else dataset
-if world > 1:  # keep the mmap fast path for the shard
-    shard.slice_uint8 = lambda a, b: dataset.slice_uint8(lo + a, lo + b)
 
-predictions = decoder.predict(shard, strategy='rerank',
+def describe_shard(decoder, dataset, world: int, rank: int,
+                   **predict_kwargs) -> List[str]:
+    """This rank's block of neurons -> captions for the whole dataset (every
+    rank returns the full list, in dataset order)."""
+    lo, hi = sharding.partition(len(dataset), world, rank)
+    shard = dataset
+    if world > 1:
+        shard = data.Subset(dataset, range(lo, hi))
+        # keep the memory-mapped uint8 fast path of `predict` for the block
+        shard.slice_uint8 = lambda a, b: dataset.slice_uint8(lo + a, lo + b)
+    mine = list(decoder.predict(shard, **predict_kwargs))
+    if world == 1:
+        return mine
+    parts: List[Sequence[str]] = [()] * world
+    torch.distributed.all_gather_object(parts, mine)
+    return [caption for part in parts for caption in part]
+
+
+def csv_rows(dataset, captions: Sequence[str]) -> List[Tuple[str, str, str]]:
+    rows = [('layer', 'unit', 'description')]
+    for index, caption in enumerate(captions):
+        layer, unit = dataset.unit(index)
+        rows.append((str(layer), str(unit), caption))
+    return rows
+
+
+def main(argv=None) -> None:
+    args = parse_args(argv)
+    rank, world, local = sharding.init_from_env()
+    device = args.device or f'cuda:{local}'
+    key = f'{args.model}/{args.dataset}'
+
+    decoder = milan.pretrained(args.milan, path=args.milan_path).to(device)
+    dataset = milannotations.load(
+        key, path=env_dir(args.data_dir, 'MILAN_DATA_DIR', 'data') / key)
+    captions = describe_shard(decoder, dataset, world, rank,
+                              strategy='rerank',
                               temperature=args.temperature,
                               beam_size=args.beam_size, device=device)
-if world > 1:
-    gathered = [None] * world
-    torch.distributed.all_gather_object(gathered, list(predictions))
-    predictions = [p for part in gathered for p in part]
+    if rank == 0:
+        out_dir = args.results_dir or env_dir(None, 'MILAN_RESULTS_DIR',
+                                              'results') / 'descriptions'
+        out_dir.mkdir(exist_ok=True, parents=True)
+        with (out_dir / f'{key.replace("/", "_")}.csv').open('w') as handle:
+            csv.writer(handle).writerows(csv_rows(dataset, captions))
+    sharding.finalize()
 
-if rank == 0:
-    results_dir.mkdir(exist_ok=True, parents=True)
-    rows = [('layer', 'unit', 'description')]
-    for index, description in enumerate(predictions):
-        layer, pos = dataset._index[index]
-        unit = int(dataset.units_by_layer[layer][pos])
-        rows.append((str(layer), str(unit), description))
-    results_csv_file = results_dir / f'{key.replace("/", "_")}.csv'
-    with results_csv_file.open('w') as handle:
-        csv.writer(handle).writerows(rows)
-sharding.finalize()
+
+if __name__ == '__main__':
+    main()

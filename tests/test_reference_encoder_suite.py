@@ -68,44 +68,37 @@ def test_pyramid_conv_encoder_init_bad_config():
         encoders.PyramidConvEncoder(config=bad)
 
 
-@pytest.fixture
-def images():
-    return torch.rand(BATCH_SIZE, *IMAGE_SHAPE)
+def random_batch(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(BATCH_SIZE, *IMAGE_SHAPE, generator=g)
+    masks = torch.randint(2, size=(BATCH_SIZE, *MASK_SHAPE), generator=g,
+                          dtype=torch.int64).float()
+    return images, masks
 
 
-@pytest.fixture
-def masks():
-    return torch.randint(2, size=(BATCH_SIZE, *MASK_SHAPE), dtype=torch.float)
+# The three forward tests of the reference (valid masks / the last two masks
+# zeroed / every mask zeroed) differ only in the masks and in which feature
+# rows must be exactly zero.
+MASK_CASES = {
+    'valid': (lambda m: m, slice(0, 0)),
+    'some_invalid': (lambda m: torch.cat([m[:-2], torch.zeros_like(m[-2:])]),
+                     slice(BATCH_SIZE - 2, BATCH_SIZE)),
+    'all_invalid': (torch.zeros_like, slice(0, BATCH_SIZE)),
+}
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', sorted(MASK_CASES))
 @pytest.mark.parametrize('config', ('resnet18', 'alexnet'))
-def test_pyramid_conv_encoder_forward(config, images, masks):
+def test_pyramid_conv_encoder_forward(config, case):
+    edit, zero_rows = MASK_CASES[case]
+    images, masks = random_batch()
     encoder = encoders.PyramidConvEncoder(config=config,
                                           pretrained=False).to('cuda')
-    actual = encoder(images, masks)
+    actual = encoder(images, edit(masks))
     assert actual.shape == (BATCH_SIZE, *encoder.feature_shape)
     assert not torch.isnan(actual).any()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('config', ('resnet18', 'alexnet'))
-def test_pyramid_conv_encoder_forward_invalid_mask(config, images, masks):
-    encoder = encoders.PyramidConvEncoder(config=config,
-                                          pretrained=False).to('cuda')
-    masks[-2:] = 0
-    actual = encoder(images, masks)
-    assert actual.shape == (BATCH_SIZE, *encoder.feature_shape)
-    assert actual[-2:].eq(0).all()
-    assert not actual[:-2].eq(0).all()
-    assert not torch.isnan(actual).any()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('config', ('resnet18', 'alexnet'))
-def test_pyramid_conv_encoder_forward_all_invalid_masks(config, images, masks):
-    encoder = encoders.PyramidConvEncoder(config=config,
-                                          pretrained=False).to('cuda')
-    actual = encoder(images, torch.zeros_like(masks))
-    assert actual.shape == (BATCH_SIZE, *encoder.feature_shape)
-    assert actual.eq(0).all()
+    expect_zero = torch.zeros(BATCH_SIZE, dtype=torch.bool)
+    expect_zero[zero_rows] = True
+    row_is_zero = actual.eq(0).all(dim=1).cpu()
+    assert torch.equal(row_is_zero, expect_zero)
