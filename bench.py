@@ -51,8 +51,9 @@ def algorithmic_gflop(beam: int, rerank: bool, k: int = 15, f: int = 3904,
     return GFLOP_ENCODER + (dec + lm) / 1e9
 
 
-def cpu_baseline(sd, nv, beam, length, temperature, sample):
-    """Time the oracle (kind 'port') on the host cores on a bounded sample."""
+def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None):
+    """Time the oracle (kind 'port') on the host cores on a bounded sample;
+    with `gpu_describe`, also check the HIP path against it on that sample."""
     from oracle import milan_oracle as O
     # torch's CPU conv collapses when oversubscribed on many-core hosts (256
     # threads: 88 s/neuron measured in round 1); cap the pool and say so.
@@ -69,9 +70,26 @@ def cpu_baseline(sd, nv, beam, length, temperature, sample):
         t0 = time.perf_counter()
         feats = O.encode(O.byte_to_float(images), masks.float(), sd, chunk=15)
         t_enc = time.perf_counter() - t0
-        O.forward(feats, sd, nv, 'rerank', length, beam, temperature)
+        want = O.forward(feats, sd, nv, 'rerank', length, beam, temperature)
         t_all = time.perf_counter() - t0
+    parity = None
+    if gpu_describe is not None:
+        # same inputs through the HIP path (untimed): the oracle as the checker
+        got = gpu_describe(images, masks)
+        tp = want['tokens'].shape[1]
+        same = (got['tokens'][:, :tp].cpu() == want['tokens']).all(dim=1)
+        parity = {
+            'neurons': sample,
+            'identical_descriptions': int(same.sum()),
+            'max_abs_feature_diff': float(
+                (got['features'].cpu() - feats).abs().max()),
+            'feature_scale': float(feats.abs().max()),
+            'max_abs_score_diff_on_identical': float(
+                (got['scores'].cpu() - want['scores'])[same].abs().max())
+            if same.any() else None,
+        }
     return {
+        'parity_vs_oracle': parity,
         'value': sample / t_all,
         'unit': 'neuron-descriptions/sec',
         'cores': torch.get_num_threads(),
@@ -329,9 +347,13 @@ def main():
         }
     if world == 1 and args.cpu_sample > 0:
         sd = synthetic.milan_state_dict(nv + 4, 'resnet101', seed=0)
-        result['cpu_baseline'] = cpu_baseline(sd, nv, beam, args.length,
-                                              args.temperature,
-                                              args.cpu_sample)
+        def gpu_describe(images, masks):
+            return ctx.describe(images, masks, strategy, args.length, beam,
+                                False, args.temperature, want_features=True)
+
+        result['cpu_baseline'] = cpu_baseline(
+            sd, nv, beam, args.length, args.temperature, args.cpu_sample,
+            gpu_describe if strategy == hip.RERANK else None)
     else:
         result['cpu_baseline'] = None
     print(json.dumps(result), flush=True)
