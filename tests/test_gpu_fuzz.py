@@ -36,7 +36,8 @@ def draw(seed):
         length=r.randint(1, 9), beam=r.randint(1, min(nv + 4, 12)),
         mi=r.random() < 0.4, temperature=r.choice([0.1, 0.2, 0.5]),
         precision=r.choice(['f32', 'split_f16']),
-        zero_every=r.choice([0, 3]))
+        zero_every=r.choice([0, 3]),
+        mask_kind=r.choice(['u8', 'float01', 'soft']))
 
 
 @pytest.mark.parametrize('seed', range(36))
@@ -57,6 +58,10 @@ def test_fuzz_encode_and_decode(seed):
                            dtype=torch.uint8, generator=g)
     masks = (torch.rand(p['n'], p['k'], 1, p['h'], p['w'], generator=g) >
              0.7).to(torch.uint8)
+    if p['mask_kind'] == 'float01':
+        masks = masks.float()
+    elif p['mask_kind'] == 'soft':  # the reference takes any float mask
+        masks = masks.float() * torch.rand(masks.shape, generator=g)
     if p['zero_every']:
         masks.view(-1, 1, p['h'], p['w'])[::p['zero_every']] = 0
     feats = O.encode(O.byte_to_float(images), masks.float(), sd, blocks=blocks)
