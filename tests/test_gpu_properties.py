@@ -4,6 +4,8 @@ CPU oracle would take minutes: determinism, neuron-permutation equivariance,
 chunk invariance, and the beam-search invariants checked THROUGH the C ABI
 (every beam score is the teacher-forced log-prob of its tokens; beams sorted;
 the rerank choice is argmax(beam_score - lambda * lm_score))."""
+import os
+
 import pytest
 import torch
 
@@ -12,7 +14,9 @@ from milan_amd import hip, synthetic
 pytestmark = pytest.mark.gpu
 
 NV, K, SIZE, BEAM, LENGTH, LAMBDA = 5000, 15, 224, 50, 15, 0.2
-N = 24  # neurons (360 images): a partial last M-tile in every conv
+# 24 neurons = 360 images: a partial last M-tile in every conv;
+# MILAN_TEST_NEURONS=256 runs the suite at the benchmark's chunk size
+N = int(os.environ.get('MILAN_TEST_NEURONS', '24'))
 
 
 @pytest.fixture(scope='module')
