@@ -59,7 +59,9 @@ typedef void* milan_stream; /* hipStream_t */
 enum {
   MILAN_TRUNK_BOTTLENECK = 0, /* taps conv1 + layer1..4, F = 61 * width      */
   MILAN_TRUNK_BASIC = 1,      /* same taps, expansion 1,   F = 16 * width      */
-  MILAN_TRUNK_ALEXNET = 2     /* taps features.0/3/6/8/10, F = 18 * width      */
+  MILAN_TRUNK_ALEXNET = 2,    /* taps features.0/3/6/8/10, F = 18 * width      */
+  MILAN_TRUNK_NONE = 3        /* decoder-only context (a foreign `Encoder`):
+                                 any feature_size % 4 == 0, trunk_* ignored   */
 };
 typedef struct milan_dims {
   int32_t trunk_width;      /* 64 for the torchvision models                */

@@ -86,19 +86,26 @@ const char* milan_last_error(void) { return g_err; }
 int milan_create(milan_ctx** out, int device, const milan_dims* dims) {
   MILAN_REQUIRE(out && dims, MILAN_ERR_ARG, "milan_create: null argument");
   const milan_dims& d = *dims;
-  MILAN_REQUIRE(d.trunk_width > 0 && d.trunk_width % 4 == 0, MILAN_ERR_SHAPE,
-                "trunk_width %d must be a positive multiple of 4", d.trunk_width);
   MILAN_REQUIRE(d.trunk_kind >= MILAN_TRUNK_BOTTLENECK &&
-                    d.trunk_kind <= MILAN_TRUNK_ALEXNET,
+                    d.trunk_kind <= MILAN_TRUNK_NONE,
                 MILAN_ERR_ARG, "unknown trunk_kind %d", d.trunk_kind);
-  const int fmul = d.trunk_kind == MILAN_TRUNK_BOTTLENECK ? 61
-                   : d.trunk_kind == MILAN_TRUNK_BASIC    ? 16
-                                                          : 18;
-  MILAN_REQUIRE(d.feature_size == fmul * d.trunk_width, MILAN_ERR_SHAPE,
-                "feature_size %d != %d * trunk_width (pyramid of five taps, "
-                "trunk_kind %d)", d.feature_size, fmul, d.trunk_kind);
-  for (int i = 0; i < 4 && d.trunk_kind != MILAN_TRUNK_ALEXNET; ++i)
-    MILAN_REQUIRE(d.trunk_blocks[i] > 0, MILAN_ERR_SHAPE, "bad trunk_blocks");
+  if (d.trunk_kind == MILAN_TRUNK_NONE) {
+    // features come from a foreign Encoder: only the decoder's GEMM alignment
+    MILAN_REQUIRE(d.feature_size > 0 && d.feature_size % 4 == 0, MILAN_ERR_SHAPE,
+                  "feature_size %d must be a positive multiple of 4",
+                  d.feature_size);
+  } else {
+    MILAN_REQUIRE(d.trunk_width > 0 && d.trunk_width % 4 == 0, MILAN_ERR_SHAPE,
+                  "trunk_width %d must be a positive multiple of 4", d.trunk_width);
+    const int fmul = d.trunk_kind == MILAN_TRUNK_BOTTLENECK ? 61
+                     : d.trunk_kind == MILAN_TRUNK_BASIC    ? 16
+                                                            : 18;
+    MILAN_REQUIRE(d.feature_size == fmul * d.trunk_width, MILAN_ERR_SHAPE,
+                  "feature_size %d != %d * trunk_width (pyramid of five taps, "
+                  "trunk_kind %d)", d.feature_size, fmul, d.trunk_kind);
+    for (int i = 0; i < 4 && d.trunk_kind != MILAN_TRUNK_ALEXNET; ++i)
+      MILAN_REQUIRE(d.trunk_blocks[i] > 0, MILAN_ERR_SHAPE, "bad trunk_blocks");
+  }
   MILAN_REQUIRE(d.hidden_size > 0 && d.hidden_size % 4 == 0 &&
                     d.embedding_size > 0 && d.embedding_size % 4 == 0 &&
                     d.attention_size > 0 && d.attention_size % 4 == 0,

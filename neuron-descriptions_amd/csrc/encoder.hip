@@ -210,6 +210,7 @@ static int pack_stem_pairs(milan_ctx* c, const Tensor* w, hipStream_t s) {
 int encoder_finalize(milan_ctx* c, hipStream_t s) {
   const std::string p = "encoder.encoder.model.";
   const int kind = c->d.trunk_kind;
+  if (kind == MILAN_TRUNK_NONE) return 0;  // decoder-only context
   if (kind == MILAN_TRUNK_ALEXNET) {
     if (!find(c, p + "features.0.weight")) return 0;  // decoder-only context
     // torchvision AlexNet.features: conv indices, strides, paddings
@@ -702,6 +703,7 @@ size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W) {
   Arena a; a.dry = true;
   const int sub = encoder_sub_batch();
   const int n = n_images < sub ? n_images : sub;
+  if (c->d.trunk_kind == MILAN_TRUNK_NONE) return 0;
   if (c->d.trunk_kind == MILAN_TRUNK_ALEXNET) {
     alexnet_workspace_dry(c, n, H, W, a);
     return a.off;

@@ -10,11 +10,12 @@ from milan_amd.decoders import (STRATEGIES, STRATEGY_BEAM, STRATEGY_GREEDY,
                                 DecoderOutput, DecoderState, DecoderStep)
 from milan_amd.encoders import Encoder, PyramidConvEncoder, encoder
 from milan_amd.lms import LanguageModel
-from milan_amd.loaders import pretrained
+from milan_amd.loaders import pretrained, pretrained_sharded
 
 __all__ = [
     'Decoder', 'DecoderOutput', 'DecoderState', 'DecoderStep', 'Encoder',
     'PyramidConvEncoder', 'LanguageModel', 'encoder', 'pretrained',
+    'pretrained_sharded',
     'STRATEGIES', 'STRATEGY_BEAM', 'STRATEGY_GREEDY', 'STRATEGY_RERANK',
     'STRATEGY_SAMPLE'
 ]

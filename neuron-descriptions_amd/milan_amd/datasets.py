@@ -59,6 +59,7 @@ class TopImagesDataset(data.Dataset):
         self.layers = tuple(sorted(str(layer) for layer in layers))
         self.images_by_layer, self.masks_by_layer, self.units_by_layer = {}, {}, {}
         self._index = []  # (layer, position)
+        self._valid = {}  # layer -> samples kept (units file may truncate)
         mode = 'r' if mmap else None
         for layer in self.layers:
             for fname in ('images.npy', 'masks.npy'):
@@ -90,8 +91,8 @@ class TopImagesDataset(data.Dataset):
             self.units_by_layer[layer] = units
             # the reference zips (units, images, masks): a units file shorter
             # than the arrays truncates the layer (datasets.py:201-204)
-            self._index += [(layer, i)
-                            for i in range(min(len(units), len(images)))]
+            self._valid[layer] = min(len(units), len(images))
+            self._index += [(layer, i) for i in range(self._valid[layer])]
         shapes = {self.images_by_layer[l].shape[1:] for l in self.layers}
         if len(shapes) != 1:
             raise ValueError(f'layers disagree on (k, 3, H, W): {shapes}')
@@ -138,12 +139,16 @@ class TopImagesDataset(data.Dataset):
         return tuple(self.unit(index) for index in indices)
 
     def slice_uint8(self, lo: int, hi: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Samples [lo, hi) as uint8 (n,k,3,H,W) / (n,k,1,H,W) CPU tensors."""
+        """Samples [lo, hi) as uint8 (n,k,3,H,W) / (n,k,1,H,W) CPU tensors
+        (same samples, in the same order, as `self[lo] .. self[hi - 1]`)."""
+        if not 0 <= lo <= hi <= len(self):
+            raise IndexError(f'slice [{lo}, {hi}) outside dataset of '
+                             f'{len(self)} samples')
         ims, mks = [], []
         pos = lo
         while pos < hi:
             layer, i = self._index[pos]
-            run = min(hi - pos, len(self.images_by_layer[layer]) - i)
+            run = min(hi - pos, self._valid[layer] - i)
             ims.append(numpy.ascontiguousarray(
                 self.images_by_layer[layer][i:i + run]))
             mks.append(numpy.ascontiguousarray(

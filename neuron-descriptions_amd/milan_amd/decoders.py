@@ -15,9 +15,10 @@ What differs by design:
   * `predict` processes `chunk_size` neurons per launch instead of 16, but
     evaluates allennlp's early-exit length T' per group of `batch_size`
     neurons, so captions / rerank choices equal the reference's batch-16 run;
-  * out of scope: training (`fit`), `score`/`bleu`/
-    `rouge`/`bert_score` (need spaCy / sacrebleu), 'sample' strategy,
-    `DecoderWithCLIP`.
+  * `score` and `strategy='sample'` are built on the same kernels (the
+    tokenizer of `score` is any callable: spaCy is not in this image);
+  * out of scope: training (`fit`), `bleu` / `rouge` /
+    `bert_score` (need sacrebleu / rouge / bert_score), `DecoderWithCLIP`.
 """
 import weakref
 from typing import (Any, Dict, Mapping, NamedTuple, Optional, Sequence, Tuple,
@@ -472,17 +473,29 @@ class Decoder(nn.Module):
             self.to(device)
         chunk = max(batch_size, (self.chunk_size // batch_size) * batch_size)
         source = dataset if features is None else features
-        fast = getattr(source, 'slice_uint8', None) if features is None else None
-        captions = []
         n = len(source)
-        spans = range(0, n, chunk)
-        if display_progress_as is not None:
+
+        def progress(iterable, total):
+            if display_progress_as is None:
+                return iterable
             try:
                 from tqdm.auto import tqdm
-                spans = tqdm(spans, desc=display_progress_as)
             except ImportError:
-                pass
-        if fast is not None and hip.torch.cuda.is_available():
+                return iterable
+            return tqdm(iterable, total=total, desc=display_progress_as)
+
+        # The uint8 fast path bypasses `__getitem__`, so it is only taken when
+        # that changes nothing: default tuple positions, no dataset-side
+        # transforms / device, no DataLoader workers requested.
+        fast = None
+        if (features is None and image_index == 2 and mask_index == 3 and
+                num_workers == 0 and torch.cuda.is_available()):
+            plain = all(getattr(dataset, attr, None) is None
+                        for attr in ('transform_images', 'transform_masks',
+                                     'device'))
+            fast = getattr(dataset, 'slice_uint8', None) if plain else None
+        captions = []
+        if fast is not None:
             # memory-mapped uint8 dataset: worker thread -> pinned staging ->
             # async H2D on a side stream, overlapped with the previous chunk
             from milan_amd import ingest
@@ -494,20 +507,14 @@ class Decoder(nn.Module):
                 return images, (masks if mask else None)
 
             chunks = ingest.ChunkPrefetcher(fetch, len(los), dev)
-            if display_progress_as is not None:
-                try:
-                    from tqdm.auto import tqdm
-                    chunks = tqdm(chunks, total=len(los),
-                                  desc=display_progress_as)
-                except ImportError:
-                    pass
-            for images, masks in chunks:
+            for images, masks in progress(chunks, len(los)):
                 with torch.no_grad():
                     output = self(images, masks, group_size=batch_size,
                                   **kwargs)
                 captions += list(output.captions)
             return tuple(captions)
-        for lo in spans:
+        spans = range(0, n, chunk)
+        for lo in progress(spans, len(spans)):
             hi = min(n, lo + chunk)
             loader = data.DataLoader(data.Subset(source, range(lo, hi)),
                                      batch_size=hi - lo,

@@ -53,7 +53,7 @@ class Dims(ctypes.Structure):
 ABI_VERSION = 2  # MILAN_ABI_VERSION this binding was written against
 
 # milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
-TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET = 0, 1, 2
+TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET, TRUNK_NONE = 0, 1, 2, 3
 _FEATURE_MULT = {TRUNK_BOTTLENECK: 61, TRUNK_BASIC: 16, TRUNK_ALEXNET: 18}
 
 
@@ -63,7 +63,7 @@ _F = ctypes.c_float
 _SZ = ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/milan_hip.h
-# declares (tests/test_abi.py checks the two against each other).
+# declares (tests/test_host.py checks the two against each other).
 SIGNATURES = {
     'milan_abi_version': (_I, []),
     'milan_last_error': (ctypes.c_char_p, []),
@@ -726,15 +726,11 @@ def make_dims(state_dict: Dict[str, torch.Tensor],
         hidden, emb, att, vocab = 4, 4, 4, n_vocab_tokens + 4
         feat = _FEATURE_MULT[kind] * width
     if width is None:
-        # decoder-only context (foreign Encoder): any geometry that satisfies
-        # milan_create's feature_size == mult * width check will do
-        for k, mult in _FEATURE_MULT.items():
-            if feat % (4 * mult) == 0:
-                kind, width = k, feat // mult
-                break
-        else:
-            raise ValueError(f'feature size {feat} is not a pyramid '
-                             '(61, 16 or 18 x a multiple of 4)')
+        # decoder-only context (foreign Encoder, like the reference accepts any
+        # `feature_shape`): no trunk, feature size only GEMM-aligned
+        if feat % 4:
+            raise ValueError(f'feature size {feat} must be a multiple of 4')
+        kind, width = TRUNK_NONE, 0
     d.trunk_kind = kind
     if vocab != n_vocab_tokens + 4:
         raise ValueError(

@@ -2,9 +2,10 @@
 
 Mirrors the inference-relevant half of the reference's `src/utils/lang.py`:
 `Vocab` (:94-172), `Indexer` special ids (:231-260), `unindex` (:573-612) and
-`reconstruct` (:678-730).  Tokenisation (spaCy; `Indexer.__call__`) is only
-needed for training / `Decoder.score` and is out of scope; the
-serialized tokenizer payload is carried opaquely so checkpoints round-trip.
+`reconstruct` (:678-730), plus `Indexer.index` / `__call__` (:331-514) for
+`Decoder.score`.  The tokenizer itself (spaCy) is not in this image: `__call__`
+takes any callable (or pre-tokenized captions) and the serialized tokenizer
+payload is carried opaquely so checkpoints round-trip.
 
 `reconstruct` is called on every (neuron, beam) sequence by the reference
 (`src/milan/decoders.py:486-487`): 4096 x 50 Python calls per run.  Here ids

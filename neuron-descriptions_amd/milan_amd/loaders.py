@@ -21,14 +21,9 @@ def models_dir() -> pathlib.Path:
     return pathlib.Path(os.environ.get(ENV_MODELS_DIR, 'models'))
 
 
-def pretrained(config: str = 'base',
-               path: Optional[os.PathLike] = None,
-               **kwargs: Any) -> decoders.Decoder:
-    """Return a pretrained MILAN model (eval mode, on CPU until `.to(device)`).
-
-    Keyword arguments go to `torch.load` (`map_location='cpu'` by default like
-    the reference's ModelConfig).
-    """
+def resolve(config: str = 'base',
+            path: Optional[os.PathLike] = None) -> pathlib.Path:
+    """Checkpoint file for a hub key (reference hubs.py:142-170), no download."""
     if config.endswith('+clip'):
         raise KeyError(f'no such model in hub: {config} (DecoderWithCLIP needs '
                        'the un-vendored CLIP package; out of scope)')
@@ -45,5 +40,54 @@ def pretrained(config: str = 'base',
             f'model path not found: {path} (no network here: place the '
             f'reference checkpoint milan-{config}.pth there, or set '
             f'{ENV_MODELS_DIR})')
+    return path
+
+
+def pretrained(config: str = 'base',
+               path: Optional[os.PathLike] = None,
+               **kwargs: Any) -> decoders.Decoder:
+    """Return a pretrained MILAN model (eval mode, on CPU until `.to(device)`).
+
+    Keyword arguments go to `torch.load` (`map_location='cpu'` by default like
+    the reference's ModelConfig).
+    """
+    path = resolve(config, path)
     kwargs.setdefault('map_location', 'cpu')
     return decoders.Decoder.load(path, **kwargs).eval()
+
+
+def pretrained_sharded(config: str = 'base',
+                       path: Optional[os.PathLike] = None,
+                       device=None,
+                       src: int = 0,
+                       **kwargs: Any) -> decoders.Decoder:
+    """`pretrained` for one-process-per-GPU jobs: only rank `src` reads the
+    checkpoint file; the module skeleton (vocabulary, constructor arguments)
+    travels as one small object broadcast and the weights as ONE flat RCCL
+    broadcast over xGMI (`sharding.broadcast_state_dict`).  Outside a process
+    group this is `pretrained(...).to(device)`.
+    """
+    import torch.distributed as dist
+
+    from milan_amd import serialize, sharding
+    if not sharding.is_distributed():
+        model = pretrained(config, path=path, **kwargs)
+        return model if device is None else model.to(device)
+    rank = dist.get_rank()
+    box, state_dict = [None], None
+    if rank == src:
+        kwargs.setdefault('map_location', 'cpu')
+        payload = serialize.load_payload(resolve(config, path), **kwargs)
+        state_dict = payload.pop('state_dict', None)
+        if state_dict is None:
+            raise ValueError('checkpoint has no state_dict')
+        box[0] = payload
+    dist.broadcast_object_list(box, src=src)
+    model = decoders.Decoder.deserialize(box[0]).eval()
+    if device is not None:
+        model = model.to(device)
+    target = model.device
+    shared = sharding.broadcast_state_dict(
+        None if state_dict is None else dict(state_dict), target, src=src)
+    model.load_state_dict(shared, strict=False)
+    return model

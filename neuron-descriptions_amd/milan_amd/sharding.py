@@ -16,15 +16,23 @@ import torch
 import torch.distributed as dist
 
 
-def partition(n: int, world: int, rank: int) -> Tuple[int, int]:
+def partition(n: int, world: int, rank: int, align: int = 1) -> Tuple[int, int]:
     """Contiguous block [lo, hi) of the neuron index owned by `rank`.
 
-    Block size ceil(n / world) (last ranks may get fewer / none); keeps the
-    reference's CSV order when shards are concatenated rank by rank.
+    Block size ceil(n / world) rounded up to a multiple of `align` (last ranks
+    may get fewer / none); keeps the reference's CSV order when shards are
+    concatenated rank by rank.  `align` = `predict`'s `batch_size` makes every
+    shard start on a batch boundary of the single-process run, so the
+    per-batch quantities of the reference (allennlp's early-exit length T',
+    which feeds the rerank LM score, decoders.py:495-512) are evaluated over
+    the same groups of neurons whatever the world size.
     """
     if world < 1 or not 0 <= rank < world:
         raise ValueError(f'bad rank/world: {rank}/{world}')
+    if align < 1:
+        raise ValueError(f'bad align: {align}')
     per = -(-n // world)
+    per = -(-per // align) * align
     lo = min(n, rank * per)
     return lo, min(n, lo + per)
 

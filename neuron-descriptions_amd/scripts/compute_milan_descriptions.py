@@ -50,10 +50,13 @@ def env_dir(value, variable: str, default: str) -> pathlib.Path:
 
 
 def describe_shard(decoder, dataset, world: int, rank: int,
-                   **predict_kwargs) -> List[str]:
+                   batch_size: int = 16, **predict_kwargs) -> List[str]:
     """This rank's block of neurons -> captions for the whole dataset (every
-    rank returns the full list, in dataset order)."""
-    lo, hi = sharding.partition(len(dataset), world, rank)
+    rank returns the full list, in dataset order).  Blocks start on multiples
+    of `batch_size`, so the reference's per-batch quantities (allennlp's
+    early-exit length) are taken over the same neurons as in a 1-process run."""
+    lo, hi = sharding.partition(len(dataset), world, rank, align=batch_size)
+    predict_kwargs['batch_size'] = batch_size
     shard = dataset
     if world > 1:
         shard = data.Subset(dataset, range(lo, hi))
@@ -81,7 +84,9 @@ def main(argv=None) -> None:
     device = args.device or f'cuda:{local}'
     key = f'{args.model}/{args.dataset}'
 
-    decoder = milan.pretrained(args.milan, path=args.milan_path).to(device)
+    # rank 0 reads the checkpoint; the others get it by RCCL broadcast
+    decoder = milan.pretrained_sharded(args.milan, path=args.milan_path,
+                                       device=device)
     dataset = milannotations.load(
         key, path=env_dir(args.data_dir, 'MILAN_DATA_DIR', 'data') / key)
     captions = describe_shard(decoder, dataset, world, rank,

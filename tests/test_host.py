@@ -285,7 +285,53 @@ def test_top_images_dataset_contract(tmp_path):
         datasets.TopImagesDataset(tmp_path)
 
 
+def test_slice_uint8_equals_getitem_when_units_file_truncates(tmp_path):
+    """A `units.npy` shorter than `images.npy` truncates that layer
+    (reference datasets.py:201-204); the uint8 fast path must hand out the
+    same samples as `__getitem__`, in the same order."""
+    import numpy
+    g = torch.Generator().manual_seed(3)
+    for layer, n_img, units in (('a', 4, [7, 9]), ('b', 3, None),
+                                ('c', 5, [1, 2, 3])):
+        d = tmp_path / layer
+        d.mkdir()
+        numpy.save(d / 'images.npy', torch.randint(
+            0, 256, (n_img, 2, 3, 8, 8), dtype=torch.uint8, generator=g).numpy())
+        numpy.save(d / 'masks.npy', torch.randint(
+            0, 2, (n_img, 2, 1, 8, 8), dtype=torch.uint8, generator=g).numpy())
+        if units is not None:
+            numpy.save(d / 'units.npy', numpy.array(units))
+    ds = datasets.TopImagesDataset(tmp_path)
+    assert len(ds) == 2 + 3 + 3
+    mul = torch.tensor(1 / 255, dtype=torch.float64).float()
+    for lo, hi in ((0, 8), (0, 5), (1, 3), (2, 7), (4, 8), (3, 3)):
+        im, mk = ds.slice_uint8(lo, hi) if hi > lo else (None, None)
+        for j in range(lo, hi):
+            s = ds[j]
+            assert torch.equal(im[j - lo].float().mul(mul), s.images), (lo, hi, j)
+            assert torch.equal(mk[j - lo].float(), s.masks)
+    with pytest.raises(IndexError):
+        ds.slice_uint8(0, 9)
+
+
 # ---- sharding ------------------------------------------------------------------
+def test_partition_alignment_keeps_the_single_process_batch_groups():
+    """Shards aligned to predict()'s batch_size: the union of the ranks'
+    batch-of-16 groups equals the 1-process run's groups (allennlp's
+    early-exit length T' is a per-group quantity and feeds the rerank score)."""
+    for n in (1000, 1152, 3904, 4096, 17, 16, 0):
+        for world in (1, 2, 3, 8):
+            want = [(a, min(n, a + 16)) for a in range(0, n, 16)]
+            got = []
+            spans = [sharding.partition(n, world, r, align=16)
+                     for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (lo, hi), nxt in zip(spans, spans[1:] + [(n, n)]):
+                assert hi == nxt[0] and (lo % 16 == 0 or lo == n)
+                got += [(a, min(hi, a + 16)) for a in range(lo, hi, 16)]
+            assert got == want, (n, world)
+
+
 def test_partition_is_contiguous_and_complete():
     for n in (0, 1, 7, 8, 4096, 1153):
         for world in (1, 2, 3, 8):
