@@ -940,8 +940,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                               nullptr, c->zero, &h2, &w2, split);
       MILAN_TRY(launch_gemm(g2, s));
       const float* identity = x;
-      if (b.has_down && split && b.c3d.ws && (long)n * h2 * w2 >= 256 &&
-          b.c3d.cout > 64) {
+      if (b.has_down && split && b.c3d.ws && b.c3d.cout > 64) {
         // c3 and the downsample as ONE GEMM over [t2 | x(strided)]
         int h3, w3;
         GemmArgs g3 = conv_args(b.c3d, pl.t2, n, h2, w2, y, EPI_BIAS_RELU,

@@ -959,7 +959,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
                          ((g.ldaux % 4 == 0) && aligned16(g.aux)));
     g.out_mode = vec_ok ? OUT_VEC4 : OUT_SCALAR;
   }
-  MILAN_REQUIRE(g.A2 == nullptr || (g.a_split && g.N > 64 && g.M >= 256 &&
+  MILAN_REQUIRE(g.A2 == nullptr || (g.a_split && g.N > 64 &&
                                     g.KH == 1 && g.KW == 1 && g.K1 % 16 == 0 &&
                                     (g.tile_hint == 0 || g.tile_hint >= 3)),
                 MILAN_ERR_SHAPE, "gemm: two-source A needs the split16 kernels");
@@ -978,13 +978,16 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     // the MFMA groups (2 workgroups per CU) is the fastest split-mode
     // configuration for every N > 64 layer; the others stay reachable through
     // tile_hint for experiments.
+    // The kernel is chosen from the LAYER (N, K) only, never from the number
+    // of rows: different tile configurations accumulate in different orders,
+    // and a description must not depend on how many neurons shared its launch
+    // (chunk size, world size).  Short M just leaves tile rows masked.
     if (g.tile_hint == 3) return launch_split16<256, 256, 4>(g, s);
-    if (g.tile_hint == 4 && g.M >= 256) return launch_split16<256, 128, 3>(g, s);
+    if (g.tile_hint == 4) return launch_split16<256, 128, 3>(g, s);
     if (g.tile_hint == 1) return launch_cfg<256, 128, 3, true, true>(g, s);
     if (g.tile_hint == 2) return launch_cfg<128, 128, 2, true, true>(g, s);
-    if (g.M >= 256 && g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);
-    if (g.M >= 256) return launch_split16<256, 128, 3>(g, s);
-    return launch_cfg<128, 128, 2, true, true>(g, s);
+    if (g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);
+    return launch_split16<256, 128, 3>(g, s);
   }
   if (g.N <= 64) {
     return cin32 ? launch_cfg<256, 64, 2, true, false>(g, s)

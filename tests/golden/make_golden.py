@@ -134,7 +134,10 @@ class _TVResNet(nn.Module):
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
-def import_reference():
+def import_reference(allennlp_beam_search=None):
+    """Import the reference with stubs for the absent third-party packages.
+    `allennlp_beam_search`: module to install as `allennlp.nn.beam_search`
+    (make_golden_beam.py passes its class-shaped stand-in)."""
     for n in [
             'spacy', 'spacy.lang', 'spacy.lang.en', 'sacrebleu', 'allennlp',
             'allennlp.nn', 'allennlp.nn.beam_search', 'rouge', 'bert_score',
@@ -145,6 +148,9 @@ def import_reference():
     ]:
         _stub(n)
     _stub('easydict', EasyDict=_EasyDict)
+    if allennlp_beam_search is not None:
+        sys.modules['allennlp.nn.beam_search'] = allennlp_beam_search
+        sys.modules['allennlp.nn'].beam_search = allennlp_beam_search
 
     class Normalize:
 

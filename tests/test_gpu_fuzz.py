@@ -77,12 +77,15 @@ def test_fuzz_encode_and_decode(seed):
                      temperature=p['temperature'])
     got = ctx.decode(feats, hip.GREEDY, length, 1, p['mi'], p['temperature'])
     top2 = want['predictions'].topk(2, dim=-1).values
-    assert_tokens_match(got['tokens'], want['tokens'],
-                        top2[..., 0] - top2[..., 1], what=str(p))
-    if torch.equal(got['tokens'].cpu(), want['tokens']):
-        close(got['predictions'], want['predictions'], 1e-4, 5e-4)
-        close(got['attentions'], want['attentions'], 1e-4, 1e-5)
-        close(got['scores'], want['scores'], 1e-4, 3e-3)
+    # random tiny vocabularies tie more often than a trained model: two rows
+    # per case may sit on a near-tie, everything else is compared
+    same = assert_tokens_match(got['tokens'], want['tokens'],
+                               top2[..., 0] - top2[..., 1], what=str(p),
+                               max_ties=2)
+    if same.any():
+        close(got['predictions'][same], want['predictions'][same], 1e-4, 5e-4)
+        close(got['attentions'][same], want['attentions'][same], 1e-4, 1e-5)
+        close(got['scores'][same], want['scores'][same], 1e-4, 3e-3)
 
     want_t, want_s = O.beam_search(feats, sd, nv, nv + 1, length, beam,
                                    mi=p['mi'], temperature=p['temperature'])
@@ -91,11 +94,11 @@ def test_fuzz_encode_and_decode(seed):
                        p['temperature'])
     tp = want_t.shape[2]
     assert int(got_b['out_len'][0]) == tp, p
-    _check_beams(got_b, want_t, want_s, tp)
-    if not p['mi'] and torch.equal(got_b['beam_tokens'].cpu()[:, :, :tp],
-                                   want_t):
+    same = _check_beams(got_b, want_t, want_s, tp, max_ties=2)
+    if not p['mi'] and same.any():
         t, s, _ = O.rerank(want_t, want_s, sd, nv, nv + 1, p['temperature'])
-        close(got_b['scores'], s, 1e-4, 3e-3)
+        picked = (got_b['tokens'].cpu()[:, :tp] == t).all(dim=1) & same
+        close(got_b['scores'][picked], s[picked], 1e-4, 3e-3)
     ctx.close()
 
 
@@ -154,5 +157,5 @@ def test_fuzz_decoder_only(seed):
         assert int(got['out_len'][gi]) == tp, (p, gi)
         part = {'beam_tokens': got['beam_tokens'][sl],
                 'beam_scores': got['beam_scores'][sl]}
-        _check_beams(part, want_t, want_s, tp)
+        _check_beams(part, want_t, want_s, tp, max_ties=2)
     ctx.close()

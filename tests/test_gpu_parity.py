@@ -167,11 +167,18 @@ def _dec(meta, dev, lm=True):
     return hip.Context(dims, sd, dev), sd, feats, meta['nvocab']
 
 
-def assert_tokens_match(got, want, gap=None, what='tokens'):
-    """Identical, or first divergence sits on an oracle near-tie."""
+MAX_TIE_ROWS = 1  # near-tie excuses allowed per test (rows / neurons)
+
+
+def assert_tokens_match(got, want, gap=None, what='tokens',
+                        max_ties=MAX_TIE_ROWS):
+    """Identical, or first divergence sits on an oracle near-tie.  Returns a
+    bool mask of the rows that are identical; at most MAX_TIE_ROWS rows may
+    take the near-tie excuse (so a pass never means "nothing was compared")."""
     got, want = got.cpu(), want.cpu()
-    if torch.equal(got, want):
-        return
+    same = (got == want).all(dim=1)
+    if bool(same.all()):
+        return same
     assert gap is not None, f'{what} differ and no tie information available'
     for b in range(want.shape[0]):
         diff = (got[b] != want[b]).nonzero()
@@ -180,6 +187,9 @@ def assert_tokens_match(got, want, gap=None, what='tokens'):
             assert gap[b, t] < 1e-4, (
                 f'{what} diverge at row {b} step {t} where the oracle top-2 gap '
                 f'is {float(gap[b, t]):.3g} (not a near-tie)')
+    assert int((~same).sum()) <= max_ties, (
+        f'{int((~same).sum())} rows of {what} took the near-tie excuse')
+    return same
 
 
 @pytest.mark.parametrize('size', ['small', 'full'])
@@ -219,23 +229,23 @@ def test_greedy_small_matches_reference_golden(dev, goldens, golden_meta, mi):
     tag = 'g4_small_mi' if mi else 'g4_small'
     out = ctx.decode(feats, hip.GREEDY, 15, 1, mi, 0.2)
     top2 = goldens[tag + '_pred'].topk(2, dim=-1).values
-    assert_tokens_match(out['tokens'], goldens[tag + '_tokens'],
-                        top2[..., 0] - top2[..., 1])
-    if torch.equal(out['tokens'].cpu(), goldens[tag + '_tokens']):
-        close(out['scores'], goldens[tag + '_scores'], 1e-4, 1e-3)
-        close(out['predictions'], goldens[tag + '_pred'], 1e-4, 2e-4)
-        close(out['attentions'], goldens[tag + '_att'], 1e-4, 1e-5)
+    same = assert_tokens_match(out['tokens'], goldens[tag + '_tokens'],
+                               top2[..., 0] - top2[..., 1])
+    assert same.any()
+    close(out['scores'][same], goldens[tag + '_scores'][same], 1e-4, 1e-3)
+    close(out['predictions'][same], goldens[tag + '_pred'][same], 1e-4, 2e-4)
+    close(out['attentions'][same], goldens[tag + '_att'][same], 1e-4, 1e-5)
     ctx.close()
 
 
 def test_greedy_full_matches_reference_golden(dev, goldens, golden_meta):
     ctx, sd, feats, nv = _dec(golden_meta['dec_full'], dev)
     out = ctx.decode(feats, hip.GREEDY, 15, 1, False, 0.2)
-    assert_tokens_match(out['tokens'], goldens['g4_full_tokens'],
-                        goldens['g4_full_top2gap'])
-    if torch.equal(out['tokens'].cpu(), goldens['g4_full_tokens']):
-        close(out['scores'], goldens['g4_full_scores'], 1e-4, 1e-3)
-        close(out['attentions'], goldens['g4_full_att'], 1e-4, 1e-5)
+    same = assert_tokens_match(out['tokens'], goldens['g4_full_tokens'],
+                               goldens['g4_full_top2gap'])
+    assert same.any()
+    close(out['scores'][same], goldens['g4_full_scores'][same], 1e-4, 1e-3)
+    close(out['attentions'][same], goldens['g4_full_att'][same], 1e-4, 1e-5)
     seqs = torch.cat(
         [torch.full((3, 1), nv, dtype=torch.long), goldens['g4_full_tokens']],
         1)
@@ -251,23 +261,57 @@ def test_lm_score_matches_reference_golden_incl_stop_quirk(
     ctx.close()
 
 
-def _check_beams(out, want_tokens, want_scores, length_used):
-    """Set-equal beams with matching scores; positional where untied."""
+def _check_beams(out, want_tokens, want_scores, length_used,
+                 max_ties=MAX_TIE_ROWS):
+    """Set-equal beams with matching scores.  A beam may be missing only if it
+    sat on the score boundary of the oracle's beam (within 2e-3 of the last
+    kept score), and at most MAX_TIE_ROWS neurons may use that excuse.
+    Returns a bool mask of the neurons whose beams are identical, in order.
+    (The goldens of the reference's own search are checked more strictly, with
+    recorded selection margins, in tests/test_gpu_beam_goldens.py.)"""
     bt = out['beam_tokens'].cpu()[:, :, :length_used]
     bs = out['beam_scores'].cpu()
     close(bs, want_scores, 1e-4, 2e-3)
     n, beam, _ = bt.shape
+    excused = 0
     for i in range(n):
         got = {tuple(bt[i, j].tolist()) for j in range(beam)}
         want = {tuple(want_tokens[i, j].tolist()) for j in range(beam)}
         missing = want - got
         # a beam may legitimately differ only if it was on the score boundary
         if missing:
+            excused += 1
             edge = want_scores[i, -1]
             for seq in missing:
                 j = [tuple(t.tolist()) for t in want_tokens[i]].index(seq)
                 assert abs(want_scores[i, j] - edge) < 2e-3, (
                     f'neuron {i}: beam {j} missing from the HIP beam set')
+    assert excused <= max_ties, (
+        f'{excused} neurons had boundary beams swapped')
+    return (bt == want_tokens).all(dim=2).all(dim=1)
+
+
+def _check_rerank(out, want_t, want_s, sd, nv, same, tprime):
+    """Top-1 after the rerank: identical tokens for every neuron whose beams
+    are identical, unless the oracle's own top-2 PMI gap is a near-tie."""
+    assert same.any(), 'no neuron left to compare the rerank choice on'
+    t, s, choice = O.rerank(want_t, want_s, sd, nv, nv + 1, 0.2)
+    b, beam, _ = want_t.shape
+    starts = want_t.new_full((b, beam, 1), nv)
+    seqs = torch.cat([starts, want_t], dim=-1).view(b * beam, -1)
+    pmi = want_s - 0.2 * O.lm_score(seqs, sd, nv + 1).view(b, beam)
+    top2 = pmi.topk(2, dim=-1).values if beam > 1 else None
+    excused = 0
+    for i in range(b):
+        if not same[i]:
+            continue
+        if torch.equal(out['tokens'].cpu()[i, :tprime], t[i]):
+            close(out['scores'][i], s[i], 1e-4, 3e-3)
+        else:
+            assert top2 is not None and float(top2[i, 0] - top2[i, 1]) < 1e-3, (
+                f'neuron {i}: rerank picked another beam without a near-tie')
+            excused += 1
+    assert excused <= MAX_TIE_ROWS
 
 
 @pytest.mark.parametrize('size,beam,length', [('small', 5, 8), ('small', 3, 15),
@@ -282,11 +326,8 @@ def test_beam_search_and_rerank_match_oracle(dev, golden_meta, size, beam,
     assert int(out['out_len'][0]) == tprime
     # beyond T' the HIP search pads with <stop>
     assert (out['beam_tokens'][:, :, tprime:] == nv + 1).all()
-    _check_beams(out, want_t, want_s, tprime)
-    if torch.equal(out['beam_tokens'].cpu()[:, :, :tprime], want_t):
-        t, s, choice = O.rerank(want_t, want_s, sd, nv, nv + 1, 0.2)
-        close(out['scores'], s, 1e-4, 3e-3)
-        assert torch.equal(out['tokens'].cpu()[:, :tprime], t)
+    same = _check_beams(out, want_t, want_s, tprime)
+    _check_rerank(out, want_t, want_s, sd, nv, same, tprime)
     # plain beam strategy = top beam
     out2 = ctx.decode(feats, hip.BEAM, length, beam, False, 0.2)
     assert torch.equal(out2['tokens'], out2['beam_tokens'][:, 0])
@@ -365,11 +406,9 @@ def test_describe_end_to_end_matches_oracle(dev, strategy):
                             top2[..., 0] - top2[..., 1])
     else:
         tp = want['beam_tokens'].shape[2]
-        _check_beams(out, want['beam_tokens'], want['beam_scores'], tp)
-        if torch.equal(out['beam_tokens'].cpu()[:, :, :tp],
-                       want['beam_tokens']):
-            assert torch.equal(out['tokens'].cpu()[:, :tp], want['tokens'])
-            close(out['scores'], want['scores'], 1e-4, 3e-3)
+        same = _check_beams(out, want['beam_tokens'], want['beam_scores'], tp)
+        _check_rerank(out, want['beam_tokens'], want['beam_scores'], sd, nv,
+                      same, tp)
     ctx.close()
 
 
