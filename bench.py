@@ -5,17 +5,32 @@ Workload (BASELINE.json `metric`): synthetic
 4096 neurons x k=15 exemplars x 3x224x224 uint8 + {0,1} masks, ResNet-101
 pyramid encoder -> attention-LSTM beam search (beam 50, length 15) -> LM (PMI)
 rerank (lambda 0.2), seeded synthetic weights, V = 5004.  A "step" is one pass
-of the hot path (milan_describe through the C ABI) over one chunk of
-`--chunk` neurons whose uint8 exemplars are already resident in HBM; the
-default 16 steps x 256 neurons = the 4096-neuron workload.  Rank r of N
-processes its own neurons (no data-path collective; weights broadcast from
-rank 0 over RCCL, results gathered at the end) => "scaling": "weak".
+of the hot path (milan_describe through the C ABI) over one chunk of `--chunk`
+neurons; the default 16 steps x 256 neurons = the 4096-neuron workload.
+
+What is timed:
+  * `value`: K steps over uint8 exemplars ALREADY RESIDENT IN HBM (the bench
+    contract), barrier + synchronize on both sides, max over ranks.
+  * `pcie_inclusive` (same number of steps, in the same run): SURVEY 8(d)'s
+    definition of the metric -- exemplars start as uint8 in PINNED HOST memory,
+    travel H2D double-buffered on a side stream (milan_amd/ingest.py), and the
+    top-1 token ids + scores are copied back to pinned host memory inside the
+    timed region.
+  * `f32_mode`: the same steps in the exact-fp32 MFMA mode (8 steps).
+  * `other_configs`: SURVEY 8(d) config 1 (256 neurons, greedy, mi=False) and
+    config 2 (1152 neurons, beam 16 + rerank) on the same GPU.
+Rank r of N describes its own neurons (no data-path collective; weights are
+broadcast from rank 0 over RCCL, results gathered at the end).  Default: every
+rank runs `--steps` chunks ("scaling": "weak").  `--neurons-total T` fixes the
+WHOLE-JOB size instead (rank r takes `partition(T, N, r, align=16)`; "scaling":
+"strong"): `--gpus 8 --neurons-total 4096` is BASELINE's metric as quoted.
 
     python bench.py                      # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8
 """
 import argparse
+import hashlib
 import json
 import os
 import pathlib
@@ -33,22 +48,47 @@ from milan_amd import hip, sharding, synthetic  # noqa: E402
 
 # algorithmic GFLOP per neuron-description.
 GFLOP_ENCODER = 233.97
-GFLOP_DECODER = {1: 0.494, 16: 6.456, 50: 19.970}
-GFLOP_LM = {16: 3.057, 50: 9.552}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, f32-in MFMA
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA (not the 2:1-sparse figure)
+PEAK_HBM_GBS = 8000.0  # HBM3E
 
 
-def algorithmic_gflop(beam: int, rerank: bool, k: int = 15, f: int = 3904,
-                      h: int = 512, a: int = 512, e: int = 128,
-                      v: int = 5004, t: int = 15) -> float:
-    """SURVEY.md 8(d) formulas, evaluated for arbitrary beam."""
+def decoder_gflop(beam: int, k: int = 15, f: int = 3904, h: int = 512,
+                  a: int = 512, e: int = 128, v: int = 5004,
+                  t: int = 15) -> float:
+    """SURVEY.md 8(d), hoisted form, per neuron."""
     rows = 1 + (t - 1) * beam
-    dec = 2 * (k * f * a + 2 * f * h + rows *
-               (h * a + k * a + h * f + k * f + (e + f + h) * 4 * h + h * v))
-    lm = 2 * beam * 16 * ((e + h) * 4 * h + 2 * h * 4 * h + h * v) if rerank \
-        else 0
-    return GFLOP_ENCODER + (dec + lm) / 1e9
+    return 2 * (k * f * a + 2 * f * h + rows *
+                (h * a + k * a + h * f + k * f +
+                 (e + f + h) * 4 * h + h * v)) / 1e9
+
+
+def lm_gflop(beam: int, rerank: bool, e: int = 128, h: int = 512,
+             v: int = 5004) -> float:
+    if not rerank:
+        return 0.0
+    return 2 * beam * 16 * ((e + h) * 4 * h + 2 * h * 4 * h + h * v) / 1e9
+
+
+def algorithmic_gflop(beam: int, rerank: bool) -> float:
+    return GFLOP_ENCODER + decoder_gflop(beam) + lm_gflop(beam, rerank)
+
+
+def pooled_bytes_per_image(masks: torch.Tensor, width: int = 64) -> float:
+    """Algorithmic bytes of the mask-weighted pooling (encoders.py:303-320):
+    only feature pixels whose bilinear-downscaled mask weight is non-zero are
+    read.  Accounting only (torch on the synthetic masks, outside any timed
+    region): a level of stride s keeps pixel (y, x) iff the central 2x2 of its
+    s x s block holds a set mask pixel."""
+    m = masks.reshape(-1, masks.shape[-2], masks.shape[-1]) != 0
+    total = 0.0
+    for stride, ch in ((2, width), (4, 4 * width), (8, 8 * width),
+                       (16, 16 * width), (32, 32 * width)):
+        a, b = stride // 2 - 1, stride // 2
+        nz = (m[:, a::stride, a::stride] | m[:, a::stride, b::stride] |
+              m[:, b::stride, a::stride] | m[:, b::stride, b::stride])
+        total += float(nz.sum()) * ch * 4
+    return total / m.shape[0]
 
 
 def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None):
@@ -101,6 +141,72 @@ def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None):
     }
 
 
+def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
+                 rerank, split, pool_bytes_img, step_ms):
+    """north_star: achieved fraction of the HBM / MFMA roofline per stage."""
+    peak_tf = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    out = []
+
+    def mfma(name, keys, label, flops_override=None):
+        ms = sum(stages[k]['region_ms'] for k in keys)
+        gemm_ms = sum(stages[k]['gemm_ms'] for k in keys)
+        flops = sum(stages[k]['gemm_flops'] for k in keys)
+        if flops_override is not None:
+            flops = flops_override
+        if ms <= 0:
+            return
+        ach = flops / (ms * 1e-3) / 1e12
+        out.append({
+            'stage': name, 'what': label, 'bound': 'mfma',
+            'ms_per_step': ms / n_steps,
+            'gemm_ms_per_step': gemm_ms / n_steps,
+            'achieved': ach, 'peak': peak_tf, 'unit': 'TFLOP/s',
+            'frac': ach / peak_tf,
+            'share_of_step': ms / n_steps / step_ms,
+        })
+
+    def hbm(name, key, label, bytes_per_image):
+        ms = stages[key]['region_ms']
+        if ms <= 0:
+            return
+        total = bytes_per_image * n_images_per_step * n_steps
+        ach = total / (ms * 1e-3) / 1e9
+        out.append({
+            'stage': name, 'what': label, 'bound': 'hbm',
+            'ms_per_step': ms / n_steps,
+            'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': ach / PEAK_HBM_GBS,
+            'algorithmic_bytes_per_image': bytes_per_image,
+            'share_of_step': ms / n_steps / step_ms,
+        })
+
+    hw = 224 * 224
+    hbm('encoder.input', 'enc_input',
+        'mask pyramid lists + u8 -> normalised NHWC input (u8 image + u8 mask '
+        'read, 16 B/pixel written)', 3 * hw + hw + 16 * hw)
+    mfma('encoder.stem', ['enc_stem'], 'conv1 7x7/2 (implicit GEMM)')
+    hbm('encoder.stem_tail', 'enc_stem_tail',
+        'bn1 + relu + maxpool 3x3/2 (112^2x64 fp32 read, 56^2x64 written)',
+        (112 * 112 * 64 + 56 * 56 * 64) * 4)
+    for i in range(1, 5):
+        mfma(f'encoder.layer{i}', [f'enc_layer{i}'],
+             f'torchvision layer{i} convolutions (implicit GEMM)')
+    hbm('encoder.pool', 'enc_pool',
+        'mask-weighted pooling of the five taps (only pixels under the mask '
+        'are read)', pool_bytes_img + 3904 * 4)
+    mfma('decoder.init', ['dec_init'],
+         'hoisted key projection + init_state GEMMs')
+    mfma('decoder.search', ['dec_search'],
+         'T-step attention-LSTM search: GEMMs + attention / top-k / beam '
+         'kernels; achieved = algorithmic decoder FLOPs / stage time '
+         '(latency- and glue-bound, not at either roof)')
+    if rerank:
+        mfma('decoder.lm_rerank', ['dec_lm'],
+             'LM scoring of every beam + PMI argmax; achieved = algorithmic '
+             'LM FLOPs / stage time')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -108,6 +214,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--chunk', type=int, default=256,
                     help='neurons per step (per GPU)')
+    ap.add_argument('--neurons-total', type=int, default=0,
+                    help='whole-job neuron count, sharded over the ranks in '
+                    'batch-aligned blocks (strong scaling; overrides --steps: '
+                    'every rank runs ceil(shard / chunk) steps).  0 = every '
+                    'rank runs --steps chunks (weak scaling, the default)')
     ap.add_argument('--beam', type=int, default=50)
     ap.add_argument('--length', type=int, default=15)
     ap.add_argument('--temperature', type=float, default=0.2)
@@ -118,24 +229,27 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=8,
                     help='neurons for the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-profile', action='store_true',
-                    help='do not bracket GEMM launches with HIP events')
+                    help='do not bracket GEMM launches / stages with HIP events')
     ap.add_argument('--pipeline', type=int, default=0,
                     help='1: run the encoder of step i+1 on a second HIP stream '
                     'while step i decodes (measured +2%% with --no-profile, 2x '
                     'slower with per-launch event profiling on); 0: strictly '
                     'serial steps (default)')
-    ap.add_argument('--from-host-steps', type=int, default=0,
-                    help='also time this many steps fed from pinned host uint8 '
-                    'tensors through the double-buffered ingest (PCIe-inclusive '
-                    'rate, reported under "pcie_inclusive"; never `value`)')
+    ap.add_argument('--from-host-steps', type=int, default=-1,
+                    help='steps of the PCIe-inclusive leg (pinned host uint8 -> '
+                    'double-buffered H2D -> describe -> D2H of tokens + scores); '
+                    '-1 = as many as the main run, 0 = skip')
     ap.add_argument('--precision', default='split_f16',
                     choices=['split_f16', 'f32'],
                     help='split_f16: operands as (hi,lo) f16 pairs, 3 f16 '
                     'MFMAs per product, fp32 accumulate (fp32-GEMM-class error, '
                     'same parity suite); f32: exact fp32-in MFMA')
-    ap.add_argument('--also-f32-steps', type=int, default=2,
+    ap.add_argument('--also-f32-steps', type=int, default=8,
                     help='extra timed steps in f32 mode, reported under '
                     '"f32_mode" (0 = skip)')
+    ap.add_argument('--other-configs', type=int, default=1,
+                    help='1: also time SURVEY 8(d) configs 1 and 2 (single-GPU '
+                    'runs only)')
     args = ap.parse_args()
 
     rank, world, local = sharding.init_from_env(args.gpus)
@@ -158,20 +272,55 @@ def main():
     strategy = {'greedy': hip.GREEDY, 'beam': hip.BEAM,
                 'rerank': hip.RERANK}[args.strategy]
     beam = 1 if strategy == hip.GREEDY else args.beam
+    rerank = strategy == hip.RERANK
+
+    # this rank's steps: (global index of the first neuron, neurons)
+    strong = args.neurons_total > 0
+    if strong:
+        lo, hi = sharding.partition(args.neurons_total, world, rank, align=16)
+        starts = list(range(lo, hi, args.chunk))
+        sizes = [min(args.chunk, hi - a) for a in starts]
+    else:
+        starts = [i * args.chunk for i in range(args.steps)]
+        sizes = [args.chunk] * args.steps
+    n_steps = len(sizes)
+    my_neurons = sum(sizes)
     # distinct resident chunks (15.4 GB of uint8 for 16); longer runs cycle
-    # through them -- every step still does the full encode + decode work
-    n_steps_data = min(max(1, args.steps), 16)
+    # through them -- every step still does the full encode + decode work.
+    # Weak mode: every rank has its own data (seed 1 + rank).  Strong mode:
+    # ONE workload indexed by the global neuron number (the same on every rank,
+    # so an N-rank run describes exactly the neurons of the 1-rank run).
+    if strong:
+        n_pool = min(-(-args.neurons_total // 16) * 16, 16 * args.chunk)
+        seed = 1
+    else:
+        n_pool = args.chunk * min(max(1, n_steps), 16)
+        seed = 1 + rank
+    n_data = max(1, n_pool // args.chunk)
     # uint8 exemplars resident in HBM before the timed region starts
-    images, masks = synthetic.exemplars(args.chunk * n_steps_data, k=15,
-                                        size=224, seed=1 + rank,
+    images, masks = synthetic.exemplars(n_pool, k=15, size=224, seed=seed,
                                         device=str(device))
+
+    def resident(start, size):
+        a = start % n_pool
+        if a + size <= n_pool:
+            return images[a:a + size], masks[a:a + size]
+        return (torch.cat([images[a:], images[:a + size - n_pool]]),
+                torch.cat([masks[a:], masks[:a + size - n_pool]]))
+
+    step_data = [resident(a, sz) for a, sz in zip(starts, sizes)]
     torch.cuda.synchronize()
 
-    def step(i):
-        lo = (i % n_steps_data) * args.chunk
-        return ctx.describe(images[lo:lo + args.chunk],
-                            masks[lo:lo + args.chunk], strategy, args.length,
-                            beam, False, args.temperature, group_size=16)
+    def chunk_of(i, size):
+        if size == sizes[i % max(1, n_steps)]:
+            return step_data[i % n_steps]
+        return resident(starts[i % n_steps], size)
+
+    def step(i, size=None, strat=None, bm=None):
+        im, mk = chunk_of(i, args.chunk if size is None else size)
+        return ctx.describe(im, mk, strategy if strat is None else strat,
+                            args.length, beam if bm is None else bm, False,
+                            args.temperature, group_size=16)
 
     for i in range(args.warmup):
         step(i)
@@ -182,24 +331,56 @@ def main():
     t0 = time.perf_counter()
     if args.pipeline and strategy != hip.GREEDY:
         # encoder of step i+1 overlaps the decode loop of step i (two streams)
-        chunks = ((images[(i % n_steps_data) * args.chunk:
-                          (i % n_steps_data + 1) * args.chunk],
-                   masks[(i % n_steps_data) * args.chunk:
-                         (i % n_steps_data + 1) * args.chunk])
-                  for i in range(args.steps))
+        chunks = (chunk_of(i, sizes[i]) for i in range(n_steps))
         outs = list(ctx.describe_pipelined(chunks, strategy, args.length, beam,
                                            False, args.temperature,
                                            group_size=16))
     else:
-        outs = [step(i) for i in range(args.steps)]
+        outs = [step(i, sizes[i]) for i in range(n_steps)]
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = time.perf_counter() - t0
-    gemm_ms = gemm_flops = gemm_launches = None
+    gemm_ms = gemm_flops = gemm_launches = stages = None
     if not args.no_profile:
         gemm_ms, gemm_flops, gemm_launches = hip.profile_read()
+        stages = hip.profile_read_stages()
         hip.profile_enable(False)
     elapsed = sharding.max_over_ranks(elapsed, device)
+
+    # ---- SURVEY 8(d) metric: pinned host uint8 in, tokens + scores on host --
+    pcie = None
+    host_steps = n_steps if args.from_host_steps < 0 else args.from_host_steps
+    if host_steps > 0:
+        from milan_amd import ingest
+        nh = min(host_steps, n_steps, 4)  # <= 0.77 GB of pinned host memory
+        host = [tuple(t.cpu().pin_memory() for t in step_data[i])
+                for i in range(nh)]
+        hsizes = [sizes[i % nh] for i in range(host_steps)]
+        tok_host = [torch.empty(sz, args.length, dtype=torch.long,
+                                pin_memory=True) for sz in hsizes]
+        sc_host = [torch.empty(sz, pin_memory=True) for sz in hsizes]
+
+        def fetch(i):
+            return host[i % nh]
+
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i, (im, mk) in enumerate(
+                ingest.ChunkPrefetcher(fetch, host_steps, device)):
+            o = ctx.describe(im, mk, strategy, args.length, beam, False,
+                             args.temperature, group_size=16)
+            tok_host[i].copy_(o['tokens'], non_blocking=True)
+            sc_host[i].copy_(o['scores'], non_blocking=True)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        e_host = sharding.max_over_ranks(time.perf_counter() - t2, device)
+        pcie = (sum(hsizes), e_host)
+        # same data, same kernels: the host leg must reproduce the resident run
+        if not args.pipeline:
+            for i in range(min(host_steps, nh)):
+                assert torch.equal(tok_host[i], outs[i]['tokens'].cpu()), i
+        del host
 
     # secondary measurement in the exact-fp32 mode (same workload, fewer steps)
     f32_mode = None
@@ -220,31 +401,45 @@ def main():
         ctx.set_precision(args.precision)
         f32_mode = (e32, ms32, n32)
 
-    pcie = None
-    if args.from_host_steps > 0:
-        from milan_amd import ingest
-        nh = min(args.from_host_steps, n_steps_data)
-        host = [(images[i * args.chunk:(i + 1) * args.chunk].cpu().pin_memory(),
-                 masks[i * args.chunk:(i + 1) * args.chunk].cpu().pin_memory())
-                for i in range(nh)]
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for im, mk in ingest.ChunkPrefetcher(lambda i: host[i % nh],
-                                             args.from_host_steps, device):
-            ctx.describe(im, mk, strategy, args.length, beam, False,
-                         args.temperature, group_size=16)
-        torch.cuda.synchronize()
-        pcie = args.from_host_steps * args.chunk / (time.perf_counter() - t2)
+    # SURVEY 8(d) configs 1 and 2 on this GPU (same weights, same kernels)
+    other = None
+    if world == 1 and args.other_configs:
+        other = []
+        for name, total, strat, bm in (
+                ('config1: 256 neurons (alexnet conv5 width), greedy, mi=False',
+                 256, hip.GREEDY, 1),
+                ('config2: 1152 neurons (alexnet all units), beam 16 + rerank',
+                 1152, hip.RERANK, 16)):
+            szs = [min(args.chunk, total - a)
+                   for a in range(0, total, args.chunk)]
+            step(0, szs[0], strat, bm)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for i, sz in enumerate(szs):
+                step(i, sz, strat, bm)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t4
+            g_alg = algorithmic_gflop(bm, strat == hip.RERANK)
+            other.append({
+                'config': name, 'neurons': total, 'steps': len(szs),
+                'value': total / dt, 'unit': 'neuron-descriptions/sec',
+                'ms': 1e3 * dt,
+                'algorithmic_tflops': g_alg * total / dt / 1e3,
+            })
 
     # final gather of the top-1 token ids + scores (section 8e); not timed
-    tokens = torch.cat([o['tokens'] for o in outs])
-    scores = torch.cat([o['scores'] for o in outs])
+    tokens = torch.cat([o['tokens'] for o in outs]) if outs else \
+        torch.empty(0, args.length, dtype=torch.long, device=device)
+    scores = torch.cat([o['scores'] for o in outs]) if outs else \
+        torch.empty(0, device=device)
     all_tokens, all_scores = sharding.gather_results(tokens, scores, dst=0)
+    counts = sharding.max_over_ranks(float(n_steps), device)
 
     if rank != 0:
         sharding.finalize()
         return
-    neurons = args.steps * args.chunk * world
+    neurons = args.neurons_total if strong else n_steps * args.chunk * world
+    assert all_tokens.shape[0] == neurons, (all_tokens.shape, neurons)
     value = neurons / elapsed
     # host-side caption reconstruction of the gathered top-1 tokens (section 8d:
     # timed and reported separately from `value`)
@@ -255,32 +450,36 @@ def main():
     captions = indexer.reconstruct(all_tokens.cpu().tolist())
     reconstruct_ms = 1e3 * (time.perf_counter() - t3)
     assert len(captions) == all_tokens.shape[0]
+    max_steps = int(counts)
     result = {
         'metric': 'neuron-descriptions/sec (whole node), 4096 neurons x k=15 '
                   'exemplars',
         'value': value,
         'unit': 'neuron-descriptions/sec',
         'n_gpus': world,
-        'steps': args.steps,
+        'steps': max_steps,
         'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps,
+        'ms_per_step': 1e3 * elapsed / max(1, max_steps),
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None,
         'dtype': ('f32' if args.precision == 'f32' else
                   'f32-equivalent: operands split into (hi,lo) f16 pairs (22 '
                   'significant bits), 3 f16 MFMAs per product, f32 accumulate'),
         'data': 'synthetic',
         'config': {
-            'workload': (f'{args.steps * args.chunk} neurons/GPU x k=15 x '
-                         f'3x224x224 u8 + masks; resnet101 pyramid encoder -> '
-                         f'attention-LSTM {args.strategy} (beam {beam}, length '
-                         f'{args.length}, lambda {args.temperature}); V='
-                         f'{nv + 4}; synthetic seeded weights'),
+            'workload': (f'{neurons} neurons x k=15 x 3x224x224 u8 + masks '
+                         f'({my_neurons} on rank 0); resnet101 pyramid encoder '
+                         f'-> attention-LSTM {args.strategy} (beam {beam}, '
+                         f'length {args.length}, lambda {args.temperature}); V='
+                         f'{nv + 4}; synthetic seeded weights; inputs resident '
+                         f'in HBM'),
             'neurons_per_step': args.chunk,
             'neurons_total': neurons,
             'parallelism': f'neuron-sharded x{world}',
             'gathered_tokens': list(all_tokens.shape),
+            'gathered_tokens_sha256': hashlib.sha256(
+                all_tokens.cpu().numpy().tobytes()).hexdigest(),
         },
         'host_reconstruct_ms': reconstruct_ms,
     }
@@ -288,21 +487,34 @@ def main():
     # rocprofv3 passes (tools/pmc_traffic.sh), so the figure is read from the
     # committed summary of those passes, not collected live.
     traffic_bytes, traffic_note = None, 'not collected (PMC needs separate rocprofv3 passes)'
-    tpath = pathlib.Path(__file__).resolve().parent / 'profiles' / 'r1_hbm_traffic.json'
-    if args.precision != 'f32' and tpath.exists():
-        with open(tpath) as f:
-            tj = json.load(f)
-        traffic_bytes = tj['traffic_gb_per_launch'] * 1e9
-        traffic_note = (f"bytes per launch of {tj['dominant_kernel']} "
-                        f"(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), offline "
-                        f"rocprofv3 --pmc passes summarised in profiles/{tpath.name}")
+    for name in ('r2_hbm_traffic.json', 'r1_hbm_traffic.json'):
+        tpath = REPO / 'profiles' / name
+        if args.precision != 'f32' and tpath.exists():
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic_bytes = tj['traffic_gb_per_launch'] * 1e9
+            traffic_note = (
+                f"bytes per launch of {tj['dominant_kernel']} (FETCH_SIZE x2 "
+                f"gfx950 correction + WRITE_SIZE), offline rocprofv3 --pmc "
+                f"passes summarised in profiles/{tpath.name}")
+            break
     if gemm_ms:
-        g_alg = algorithmic_gflop(beam, strategy == hip.RERANK)
-        per_launch_flop = g_alg * 1e9 * args.steps * args.chunk / gemm_launches
+        g_alg = algorithmic_gflop(beam, rerank)
+        per_launch_flop = g_alg * 1e9 * my_neurons / gemm_launches
         avg_ms = gemm_ms / gemm_launches
         achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
         split = args.precision != 'f32'
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        # per stage: the decode stages are priced with SURVEY's algorithmic
+        # FLOPs (what `achieved` above uses), the encoder stages with the
+        # un-padded 2*M*N*K of their own launches (sums to 233.97 GFLOP/neuron)
+        if stages is not None:
+            stages['dec_search']['gemm_flops'] = (
+                decoder_gflop(beam) * 1e9 * my_neurons -
+                stages['dec_init']['gemm_flops'])
+            stages['dec_lm']['gemm_flops'] = lm_gflop(beam, rerank) * 1e9 * \
+                my_neurons
+        pool_bytes = pooled_bytes_per_image(masks[:args.chunk])
         result['roofline'] = {
             'bound': 'mfma',
             'kernel': ('igemm_split16_kernel / igemm_kernel<SPLIT> '
@@ -320,21 +532,30 @@ def main():
             'launches': gemm_launches,
             'avg_launch_ms': avg_ms,
             'algorithmic_gflop_per_neuron': g_alg,
-            'counted_gflop_per_neuron':
-                gemm_flops / 1e9 / (args.steps * args.chunk),
+            'counted_gflop_per_neuron': gemm_flops / 1e9 / my_neurons,
             'gemm_time_frac_of_step': gemm_ms * 1e-3 / elapsed,
+            'stages': stage_report(stages, n_steps, my_neurons * 15 / n_steps,
+                                   args.chunk, beam, rerank, split, pool_bytes,
+                                   1e3 * elapsed / n_steps)
+            if stages is not None else None,
         }
     else:
         result['roofline'] = None
     if pcie is not None:
+        n_host, e_host = pcie
         result['pcie_inclusive'] = {
-            'value': pcie * world, 'unit': 'neuron-descriptions/sec',
-            'steps': args.from_host_steps,
-            'note': 'pinned host uint8 -> pinned staging -> async H2D on a '
-                    'side stream, double buffered (milan_amd/ingest.py)'}
+            'value': n_host * world / e_host,
+            'unit': 'neuron-descriptions/sec',
+            'steps': host_steps,
+            'frac_of_value': n_host * world / e_host / value,
+            'note': 'SURVEY 8(d) metric: uint8 exemplars in pinned host memory '
+                    '-> async H2D on a side stream, double buffered '
+                    '(milan_amd/ingest.py) -> milan_describe -> top-1 tokens + '
+                    'scores copied to pinned host memory; all inside the timed '
+                    'region, same steps as `value`'}
     if f32_mode is not None:
         e32, ms32, n32 = f32_mode
-        g_alg = algorithmic_gflop(beam, strategy == hip.RERANK)
+        g_alg = algorithmic_gflop(beam, rerank)
         n32_neurons = args.also_f32_steps * args.chunk
         result['f32_mode'] = {
             'value': n32_neurons * world / e32,
@@ -345,15 +566,18 @@ def main():
                 g_alg * 1e9 * n32_neurons / (ms32 * 1e-3) / 1e12 /
                 PEAK_F32_MFMA_TFLOPS,
         }
+    if other is not None:
+        result['other_configs'] = other
     if world == 1 and args.cpu_sample > 0:
         sd = synthetic.milan_state_dict(nv + 4, 'resnet101', seed=0)
+
         def gpu_describe(images, masks):
             return ctx.describe(images, masks, strategy, args.length, beam,
                                 False, args.temperature, want_features=True)
 
         result['cpu_baseline'] = cpu_baseline(
             sd, nv, beam, args.length, args.temperature, args.cpu_sample,
-            gpu_describe if strategy == hip.RERANK else None)
+            gpu_describe if rerank else None)
     else:
         result['cpu_baseline'] = None
     print(json.dumps(result), flush=True)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MILAN_ABI_VERSION 2
+#define MILAN_ABI_VERSION 3
 
 enum {
   MILAN_OK = 0,
@@ -231,6 +231,31 @@ int milan_get_precision(const milan_ctx* ctx);
 int milan_profile_enable(int enable);
 int milan_profile_read(double* gemm_ms, double* gemm_flops,
                        long long* gemm_launches);
+
+/* Per-stage breakdown of the same measurement (north_star: "fraction of
+ * HBM/MFMA roofline reported per stage").  While profiling is enabled every
+ * stage region of the hot path is also bracketed by two HIP events and every
+ * GEMM record carries the stage it ran in.  `table` receives
+ * MILAN_STAGE_COUNT rows of 5 doubles: region ms (sum over calls), region
+ * count, GEMM ms inside the stage, GEMM algorithmic FLOPs, GEMM launches. */
+enum milan_stage {
+  MILAN_STAGE_OTHER = 0,
+  MILAN_STAGE_ENC_INPUT = 1,     /* mask pyramid lists + u8 -> normalised input
+                                    (datasets.py:191-197, encoders.py:295)   */
+  MILAN_STAGE_ENC_STEM = 2,      /* conv1 7x7/2                               */
+  MILAN_STAGE_ENC_STEM_TAIL = 3, /* bn1 + relu + maxpool 3x3/2                */
+  MILAN_STAGE_ENC_LAYER1 = 4,    /* torchvision layer1..layer4 (convs only)   */
+  MILAN_STAGE_ENC_LAYER2 = 5,
+  MILAN_STAGE_ENC_LAYER3 = 6,
+  MILAN_STAGE_ENC_LAYER4 = 7,
+  MILAN_STAGE_ENC_POOL = 8,      /* mask-weighted pooling of the five taps
+                                    (encoders.py:303-320)                    */
+  MILAN_STAGE_DEC_INIT = 9,      /* hoisted key projection + init_state       */
+  MILAN_STAGE_DEC_SEARCH = 10,   /* the T-step greedy / beam loop             */
+  MILAN_STAGE_DEC_LM = 11,       /* LM scoring of the beams + rerank select   */
+  MILAN_STAGE_COUNT = 12
+};
+int milan_profile_read_stages(double* table /* [MILAN_STAGE_COUNT][5] */);
 
 /* Building block exposed for kernel-level parity tests: one NHWC fp32
  * convolution through the same implicit-GEMM MFMA kernel the trunk uses

@@ -457,6 +457,11 @@ int milan_profile_read(double* gemm_ms, double* gemm_flops,
   return gemm_profile_read(gemm_ms, gemm_flops, gemm_launches);
 }
 
+int milan_profile_read_stages(double* table) {
+  MILAN_REQUIRE(table, MILAN_ERR_ARG, "milan_profile_read_stages: null table");
+  return profile_read_stages(table);
+}
+
 int milan_describe(milan_ctx* c, const void* images, int image_dtype,
                    const void* masks, int mask_dtype, int n, int k, int height,
                    int width, int strategy, int length, int beam_size, int mi,

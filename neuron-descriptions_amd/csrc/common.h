@@ -95,6 +95,20 @@ int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
 int gemm_profile_enable(int enable);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, long long* launches);
+int profile_read_stages(double* table /* [MILAN_STAGE_COUNT][5] */);
+// RAII bracket of one stage region on a stream: labels the GEMM launches made
+// inside it and, while profiling is on, times the region with two HIP events.
+class StageScope {
+ public:
+  StageScope(int stage, hipStream_t s);
+  ~StageScope();
+  StageScope(const StageScope&) = delete;
+  StageScope& operator=(const StageScope&) = delete;
+ private:
+  hipStream_t stream_;
+  int prev_;
+  long idx_;
+};
 
 inline GemmArgs linear_args(const float* A, long lda, const float* W,
                             const float* bias, float* C, int ldc, int M, int N,

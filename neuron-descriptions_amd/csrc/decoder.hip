@@ -16,6 +16,7 @@
 // beam row (68% of the reference decoder's FLOPs).
 #include "common.h"
 #include <limits>
+#include <optional>
 
 namespace milan {
 
@@ -1291,8 +1292,11 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   const int R = n * beam;
   const int Hl = d.lm_hidden_size;
 
-  MILAN_TRY(project_keys(c, features, n * k, b.keys, s));
-  MILAN_TRY(init_state_impl(c, features, n, k, b.pooled, b.h, b.cc, s));
+  {
+    StageScope scope(MILAN_STAGE_DEC_INIT, s);
+    MILAN_TRY(project_keys(c, features, n * k, b.keys, s));
+    MILAN_TRY(init_state_impl(c, features, n, k, b.pooled, b.h, b.cc, s));
+  }
   hipLaunchKernelGGL(fill_i64_kernel, dim3(nblk(n)), dim3(256), 0, s, b.tok,
                      (long)n, (int64_t)d.start_index);
   int lmcur = 0;
@@ -1303,6 +1307,7 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   }
 
   if (greedy) {
+    StageScope scope(MILAN_STAGE_DEC_SEARCH, s);
     float *h = b.h, *cc = b.cc, *hn = b.hn, *cn = b.cn;
     for (int t = 0; t < length; ++t) {
       MILAN_TRY(step_core(c, features, b.keys, n, 1, k, b.tok, h, cc, hn, cn, &b, s));
@@ -1337,6 +1342,8 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   MILAN_REQUIRE(merge_lds <= 64 * 1024, MILAN_ERR_ARG,
                 "beam_size %d too large for the merge kernel", beam);
   int beam_prev = 1, rows = n, lpcur = 0;
+  std::optional<StageScope> search_scope;
+  search_scope.emplace(MILAN_STAGE_DEC_SEARCH, s);
   for (int t = 0; t < length; ++t) {
     MILAN_TRY(step_core(c, features, b.keys, rows, beam_prev, k, b.tok, b.h, b.cc,
                         b.hn, b.cn, &b, s));
@@ -1373,6 +1380,8 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   int32_t* lens = out_len ? out_len : b.len1 + n + 1;  // scratch if not wanted
   hipLaunchKernelGGL(group_len_kernel, dim3(groups), dim3(256), 0, s, b.hist_tok,
                      n, beam, length, group_size, d.stop_index, lens);
+  search_scope.reset();
+  StageScope lm_scope(MILAN_STAGE_DEC_LM, s);
   const float* lm_scores = nullptr;
   if (strategy == MILAN_RERANK) {
     hipLaunchKernelGGL(build_lm_seqs_kernel, dim3(nblk((long)R * (length + 1))),

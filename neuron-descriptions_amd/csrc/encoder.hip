@@ -10,6 +10,7 @@
 // (nethook retains 'conv1' before bn1/relu, src/deps/netdissect/nethook.py:
 // 226-235); bn1+relu+maxpool run as one fused kernel.
 #include "common.h"
+#include <optional>
 
 #include <cstdlib>
 
@@ -814,6 +815,8 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   const int F = c->d.feature_size;
 
   // 1. masks -> per-level normalised sparse weight lists
+  std::optional<StageScope> stage;  // current profiling region (RAII)
+  stage.emplace(MILAN_STAGE_ENC_INPUT, s);
   if (spatial) {
     // no pooling
   } else if (masks == nullptr || mask_dtype == MILAN_DTYPE_U8)
@@ -861,9 +864,11 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                          (float4*)pl.in4, mul, mul_u8);
     MILAN_CHECK_HIP(hipGetLastError());
   }
+  stage.reset();
 
   auto pool = [&](const float* tap, int level, int C, int col_off) -> int {
     if (spatial) return 0;
+    StageScope scope(MILAN_STAGE_ENC_POOL, s);
     const int P = pl.lv.h[level] * pl.lv.w[level];
     if (split && level > 0)
       hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
@@ -891,8 +896,12 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       g.aniso = 1; g.stride_w = 1; g.pad_w = 1;
       g.out_split = 0;  // the raw fp32 output is pyramid tap 0
     }
-    MILAN_TRY(launch_gemm(g, s));
+    {
+      StageScope scope(MILAN_STAGE_ENC_STEM, s);
+      MILAN_TRY(launch_gemm(g, s));
+    }
     MILAN_TRY(pool(pl.raw, 0, wd, 0));
+    stage.emplace(MILAN_STAGE_ENC_STEM_TAIL, s);
     const long total = (long)n * pl.hp * pl.wp * (wd / (split ? 8 : 4));
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (split)
@@ -905,12 +914,14 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                          pl.wp, (const float4*)c->bn1_scale,
                          (const float4*)c->bn1_shift, (float4*)pl.x0);
     MILAN_CHECK_HIP(hipGetLastError());
+    stage.reset();
   }
 
   // 4. bottleneck stages; tap after each stage
   float *x = pl.x0, *y = pl.x1;
   int h = pl.hp, w = pl.wp, col = wd;
   for (int li = 0; li < 4; ++li) {
+    stage.emplace(MILAN_STAGE_ENC_LAYER1 + li, s);
     for (const Bottleneck& b : c->blocks[li]) {
       int h1, w1, h2, w2, h3, w3;
       if (b.basic) {
@@ -971,6 +982,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       float* tmp = x; x = y; y = tmp;
       h = h3; w = w3;
     }
+    stage.reset();
     const int C = (c->d.trunk_kind == MILAN_TRUNK_BASIC ? wd : wd * 4) << li;
     MILAN_REQUIRE(h == pl.lv.h[li + 1] && w == pl.lv.w[li + 1], MILAN_ERR_SHAPE,
                   "internal: stage %d geometry mismatch", li + 1);

@@ -856,36 +856,91 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 }
 
 // ---- live kernel timing (bench.py's roofline leg) ---------------------------
-// HIP events are recorded on the launch stream right before/after each GEMM
-// launch while profiling is enabled; durations are read back after a sync.
-struct GemmProfiler {
-  bool on = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-  size_t used = 0;
+// While profiling is enabled, HIP events are recorded on the launch stream
+// right before/after every GEMM launch and around every stage region
+// (StageScope, common.h); durations are read back after a sync.  A GEMM record
+// carries the stage it was launched in.
+struct ProfRec {
+  hipEvent_t a = nullptr, b = nullptr;
+  int stage = 0;
+  bool gemm = false;
   double flops = 0.0;
 };
-static GemmProfiler g_prof;
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> rec;
+  size_t used = 0;
+  int stage = MILAN_STAGE_OTHER;
+};
+static Profiler g_prof;
+
+static ProfRec* prof_next() {
+  if (g_prof.used == g_prof.rec.size()) {
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess)
+      return nullptr;
+    g_prof.rec.push_back(r);
+  }
+  return &g_prof.rec[g_prof.used++];
+}
 
 int gemm_profile_enable(int enable) {
   g_prof.on = enable != 0;
   g_prof.used = 0;
-  g_prof.flops = 0.0;
+  g_prof.stage = MILAN_STAGE_OTHER;
   return 0;
 }
 
 bool gemm_profile_active() { return g_prof.on; }
 
+StageScope::StageScope(int stage, hipStream_t s) : stream_(s) {
+  prev_ = g_prof.stage;
+  g_prof.stage = stage;
+  idx_ = -1;
+  if (!g_prof.on) return;
+  ProfRec* r = prof_next();
+  if (!r) return;
+  r->stage = stage; r->gemm = false; r->flops = 0.0;
+  idx_ = (long)(g_prof.used - 1);
+  (void)hipEventRecord(r->a, s);
+}
+
+StageScope::~StageScope() {
+  g_prof.stage = prev_;
+  if (idx_ >= 0 && (size_t)idx_ < g_prof.used)
+    (void)hipEventRecord(g_prof.rec[idx_].b, stream_);
+}
+
 int gemm_profile_read(double* ms, double* flops, long long* launches) {
   MILAN_CHECK_HIP(hipDeviceSynchronize());
-  double total = 0.0;
+  double total = 0.0, fl = 0.0;
+  long long n = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
+    const ProfRec& r = g_prof.rec[i];
+    if (!r.gemm) continue;
     float t = 0.f;
-    MILAN_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
-    total += t;
+    MILAN_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    total += t; fl += r.flops; ++n;
   }
   if (ms) *ms = total;
-  if (flops) *flops = g_prof.flops;
-  if (launches) *launches = (long long)g_prof.used;
+  if (flops) *flops = fl;
+  if (launches) *launches = n;
+  return 0;
+}
+
+// table[stage][0..4] = region ms, region count, gemm ms, gemm flops, gemm launches
+int profile_read_stages(double* table) {
+  MILAN_CHECK_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < MILAN_STAGE_COUNT * 5; ++i) table[i] = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    const ProfRec& r = g_prof.rec[i];
+    if (r.stage < 0 || r.stage >= MILAN_STAGE_COUNT) continue;
+    float t = 0.f;
+    MILAN_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    double* row = table + r.stage * 5;
+    if (r.gemm) { row[2] += t; row[3] += r.flops; row[4] += 1.0; }
+    else { row[0] += t; row[1] += 1.0; }
+  }
   return 0;
 }
 
@@ -1011,17 +1066,14 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
                 "gemm: Cin=%d / strides must be multiples of 4 floats and "
                 "operands 16-byte aligned", g.Cin);
   if (!g_prof.on) return launch_gemm_impl(g, s);
-  if (g_prof.used == g_prof.ev.size()) {
-    hipEvent_t a, b;
-    MILAN_CHECK_HIP(hipEventCreate(&a));
-    MILAN_CHECK_HIP(hipEventCreate(&b));
-    g_prof.ev.emplace_back(a, b);
-  }
-  auto& e = g_prof.ev[g_prof.used++];
-  MILAN_CHECK_HIP(hipEventRecord(e.first, s));
+  ProfRec* e = prof_next();
+  MILAN_REQUIRE(e != nullptr, MILAN_ERR_STATE, "profiler: cannot create events");
+  e->stage = g_prof.stage;
+  e->gemm = true;
+  e->flops = 2.0 * (double)g.M * (double)g.N * (double)(g.flop_k > 0 ? g.flop_k : g.K);
+  MILAN_CHECK_HIP(hipEventRecord(e->a, s));
   const int r = launch_gemm_impl(g, s);
-  MILAN_CHECK_HIP(hipEventRecord(e.second, s));
-  g_prof.flops += 2.0 * (double)g.M * (double)g.N * (double)(g.flop_k > 0 ? g.flop_k : g.K);
+  MILAN_CHECK_HIP(hipEventRecord(e->b, s));
   return r;
 }
 

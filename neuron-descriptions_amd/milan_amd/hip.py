@@ -50,7 +50,7 @@ class Dims(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 2  # MILAN_ABI_VERSION this binding was written against
+ABI_VERSION = 3  # MILAN_ABI_VERSION this binding was written against
 
 # milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
 TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET, TRUNK_NONE = 0, 1, 2, 3
@@ -104,6 +104,7 @@ SIGNATURES = {
         ctypes.POINTER(ctypes.c_double),
         ctypes.POINTER(ctypes.c_longlong)
     ]),
+    'milan_profile_read_stages': (_I, [ctypes.POINTER(ctypes.c_double)]),
     'milan_conv2d_nhwc':
         (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I,
               _P]),
@@ -672,6 +673,21 @@ def profile_read():
     _check(load_library().milan_profile_read(ctypes.byref(ms), ctypes.byref(fl),
                                              ctypes.byref(n)))
     return ms.value, fl.value, n.value
+
+
+STAGES = ('other', 'enc_input', 'enc_stem', 'enc_stem_tail', 'enc_layer1',
+          'enc_layer2', 'enc_layer3', 'enc_layer4', 'enc_pool', 'dec_init',
+          'dec_search', 'dec_lm')  # enum milan_stage
+
+
+def profile_read_stages() -> Dict[str, Dict[str, float]]:
+    """Per-stage HIP-event timings since profile_enable(True): region ms and
+    count, plus the GEMM ms / algorithmic FLOPs / launches inside the stage."""
+    table = (ctypes.c_double * (len(STAGES) * 5))()
+    _check(load_library().milan_profile_read_stages(table))
+    keys = ('region_ms', 'regions', 'gemm_ms', 'gemm_flops', 'gemm_launches')
+    return {name: dict(zip(keys, table[i * 5:i * 5 + 5]))
+            for i, name in enumerate(STAGES)}
 
 
 def conv2d_nhwc(x: torch.Tensor,

@@ -39,6 +39,8 @@ class ChunkPrefetcher:
     def _pin_like(self, slot: int, t: Optional[torch.Tensor], which: int):
         if t is None:
             return None
+        if t.is_pinned():
+            return t  # already DMA-able: no staging copy
         bufs = self._pinned[slot] or [None, None]
         buf = bufs[which]
         if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
