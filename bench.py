@@ -346,6 +346,14 @@ def main():
         stages = hip.profile_read_stages()
         hip.profile_enable(False)
     elapsed = sharding.max_over_ranks(elapsed, device)
+    if os.environ.get('MILAN_BENCH_DEBUG'):  # per-rank checksums on stderr
+        def h(t):
+            return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:12]
+        for i, o in enumerate(outs):
+            print(f'[rank {rank}] step {i} start {starts[i]} size {sizes[i]} '
+                  f'images {h(step_data[i][0])} masks {h(step_data[i][1])} '
+                  f'tokens {h(o["tokens"])} scores {h(o["scores"])}',
+                  file=sys.stderr, flush=True)
 
     # ---- SURVEY 8(d) metric: pinned host uint8 in, tokens + scores on host --
     pcie = None

@@ -216,23 +216,24 @@ __global__ __launch_bounds__(256) void attend_kernel(
 }
 
 // ctx[r][f] = sum_k att[r][k] * features[neuron][k][f]   (decoders.py:613)
+// The k attention weights of the row are wave-uniform: they are read straight
+// from global memory (scalar loads), no LDS staging and no barrier.
 __global__ __launch_bounds__(256) void context_kernel(
     const float* __restrict__ att, const float* __restrict__ feat, int rpn,
     int k, int F, float* __restrict__ ctx) {
-  __shared__ float a[64];
   const int r = blockIdx.x;
-  if (threadIdx.x < k) a[threadIdx.x] = att[(long)r * k + threadIdx.x];
-  __syncthreads();
-  const float4* f4 = reinterpret_cast<const float4*>(feat + (long)(r / rpn) * k * F);
-  const int F4 = F >> 2;
-  for (int f = blockIdx.y * 256 + threadIdx.x; f < F4; f += gridDim.y * 256) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* ar = att + (long)r * k;
+  const float* fr = feat + (long)(r / rpn) * k * F;
+  for (int f = (blockIdx.y * 256 + threadIdx.x) * 4; f < F;
+       f += gridDim.y * 1024) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int j = 0; j < k; ++j) {
-      const float4 v = f4[(long)j * F4 + f];
-      const float aj = a[j];
-      s.x += aj * v.x; s.y += aj * v.y; s.z += aj * v.z; s.w += aj * v.w;
+      const float4 v = *reinterpret_cast<const float4*>(fr + (long)j * F + f);
+      const float aj = ar[j];
+      s0 = fmaf(aj, v.x, s0); s1 = fmaf(aj, v.y, s1);
+      s2 = fmaf(aj, v.z, s2); s3 = fmaf(aj, v.w, s3);
     }
-    reinterpret_cast<float4*>(ctx + (long)r * F)[f] = s;
+    *reinterpret_cast<float4*>(ctx + (long)r * F + f) = make_float4(s0, s1, s2, s3);
   }
 }
 

@@ -1,5 +1,6 @@
 """Shared pytest configuration: paths, markers, golden fixtures."""
 import json
+import os
 import pathlib
 import sys
 
@@ -12,6 +13,11 @@ for p in (REPO, REPO / 'neuron-descriptions_amd'):
         sys.path.insert(0, str(p))
 
 GOLDEN_DIR = REPO / 'tests' / 'golden'
+
+# torch's CPU convolutions collapse when oversubscribed on many-core hosts (the
+# GPU box has 256 hardware threads: 88 s per neuron for the oracle's ResNet-101
+# measured in round 1, against 0.5 s on 32 threads).
+torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
 def pytest_configure(config):
