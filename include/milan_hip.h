@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MILAN_ABI_VERSION 3
+#define MILAN_ABI_VERSION 4
 
 enum {
   MILAN_OK = 0,
@@ -256,6 +256,87 @@ enum milan_stage {
   MILAN_STAGE_COUNT = 12
 };
 int milan_profile_read_stages(double* table /* [MILAN_STAGE_COUNT][5] */);
+
+/* ---- exemplar computation ---------------------------
+ * The stage that WRITES the images.npy / masks.npy this path reads
+ * (src/exemplars/compute.py:27-246).  The dissected model stays the caller's
+ * (the reference takes it as two black-box functions, compute.py:27-29);
+ * these entry points are the tensor operations of its netdissect
+ * dependencies on the activation tensor `hiddens` (batch, channels, h, w)
+ * fp32 NCHW, hw = h * w.  `units` (device int32 [n_units], or NULL = all
+ * channels) is the `units=` subset of compute.py:186-199.  The control flow of
+ * the quantile sketch (which level is compacted when, with which random bit)
+ * is host logic, as it is Python in the reference (milan_amd/exemplars.py). */
+
+/* RunningTopK.add + result (src/deps/netdissect/runningstats.py:58-116) on the
+ * spatial max of compute.py:331: merges this batch into top_values/top_index
+ * [n_units][k], of which `filled` columns are valid; afterwards
+ * min(k, filled + batch) are, sorted by value descending (equal values: lower
+ * dataset index first).  Image b of the batch has dataset index
+ * first_index + b.  pooled_scratch: n_units * batch floats.
+ * filled + batch <= 2048. */
+int milan_exemplar_topk_update(const float* hiddens, int batch, int channels,
+                               int hw, const int32_t* units, int n_units,
+                               int64_t first_index, int k, int filled,
+                               float* pooled_scratch, float* top_values,
+                               int64_t* top_index, milan_stream stream);
+
+/* RunningQuantile._add_every's copy (runningstats.py:363-385): activation rows
+ * [first, first + count) of hiddens.permute(0,2,3,1).reshape(-1, C) go,
+ * transposed, into level0[n_units][capacity] at columns column.. */
+int milan_exemplar_sketch_append(const float* hiddens, int batch, int channels,
+                                 int hw, const int32_t* units, int n_units,
+                                 int64_t first, int64_t count, float* level0,
+                                 int64_t capacity, int64_t column,
+                                 milan_stream stream);
+
+/* One compaction of RunningQuantile._shift / _expand (runningstats.py:387-407,
+ * 485-521): every row's first n columns of src are sorted ascending, every
+ * second element starting at `offset` (the random bit) is written to dst at
+ * columns position.., and -- when `extremes` [n_units][2] is given -- the
+ * row's minimum / maximum are folded into it (:415-419).  dst may equal src
+ * (the in-place "scrunch") with position 0.  Workspace:
+ * milan_exemplar_sort_workspace(n_units, n, 0). */
+size_t milan_exemplar_sort_workspace(int n_units, int64_t n, int pairs);
+int milan_exemplar_sketch_compact(const float* src, int64_t src_capacity,
+                                  int64_t n, int n_units, int offset, float* dst,
+                                  int64_t dst_capacity, int64_t position,
+                                  float* extremes, void* workspace,
+                                  size_t workspace_bytes, milan_stream stream);
+
+/* RunningQuantile.quantiles(q) for one q (runningstats.py:531-580): weighted
+ * summary of all levels (level l has weight 2^l), stable sort, float32
+ * cumulative weights, numpy.interp in float64 -> out [n_units] float32.
+ * levels / firstfree / capacities are HOST arrays of n_levels entries (device
+ * row pointers, fill counts, row capacities); extremes [n_units][2] is updated
+ * with the level-0 remainder like the reference does.  Exact parity needs the
+ * total weight (= samples seen) below 2^24 per unit (float32 sums, as in the
+ * reference).  Workspace: milan_exemplar_sort_workspace(n_units, sum of
+ * firstfree, 1). */
+int milan_exemplar_sketch_quantile(const float* const* levels,
+                                   const int64_t* firstfree,
+                                   const int64_t* capacities, int n_levels,
+                                   int n_units, float* extremes, float q,
+                                   float* out, void* workspace,
+                                   size_t workspace_bytes, milan_stream stream);
+
+/* ImageVisualizer cells (src/deps/ext/netdissect/imgviz.py:56-81): for each of
+ * the n_cells rows (batch item, activation channel, unit slot, rank) of `cells`
+ * (device int32 [n_cells][4]):
+ *   mask   = grid_sample(act, upsample_grid, bilinear, align_corners) > level
+ *            (imgviz.py:185-198, upsample.py:6-45,132-156)        -> out_masks
+ *   image  = nearest resize of (image * mul + add).clamp(0,255).byte()
+ *            (imgviz.py:200-210, renormalize.py:119-136)          -> out_images
+ *   masked = image inside the mask, 0.25 * image outside          -> out_masked
+ * written at [slot][rank] of the (slots, k, 3|1, out, out) uint8 outputs.
+ * images (batch, 3, img_h, img_w) fp32; levels [slots] fp32 (device);
+ * mul3 / add3 host float[3]. */
+int milan_exemplar_render(const float* hiddens, int batch, int channels, int h,
+                          int w, const float* images, int img_h, int img_w,
+                          const int32_t* cells, int n_cells, const float* levels,
+                          const float* mul3, const float* add3, int out_size,
+                          int k, uint8_t* out_images, uint8_t* out_masks,
+                          uint8_t* out_masked, milan_stream stream);
 
 /* Building block exposed for kernel-level parity tests: one NHWC fp32
  * convolution through the same implicit-GEMM MFMA kernel the trunk uses

@@ -895,6 +895,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       g.M = n * ho * wo;
       g.aniso = 1; g.stride_w = 1; g.pad_w = 1;
       g.out_split = 0;  // the raw fp32 output is pyramid tap 0
+      g.flop_k = c->stem.kh * c->stem.kw * c->stem.cin_real;  // 7x7x3 = 147
     }
     {
       StageScope scope(MILAN_STAGE_ENC_STEM, s);

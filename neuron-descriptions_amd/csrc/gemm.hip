@@ -40,6 +40,7 @@
 //   sees 16-byte per-lane accesses covering whole 256-B row segments.
 #include "common.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -986,9 +987,34 @@ static int env_tile_hint() {
   return v;
 }
 
+// experiments only: MILAN_TILE_OVERRIDE="N:K:hint,N:K:hint" forces a tile
+// configuration for the layers with that (N, K)
+static int env_tile_override(int N, int K) {
+  static std::vector<int> table;
+  static bool parsed = false;
+  if (!parsed) {
+    parsed = true;
+    const char* e = getenv("MILAN_TILE_OVERRIDE");
+    while (e && *e) {
+      int n = 0, k = 0, h = 0, used = 0;
+      if (sscanf(e, "%d:%d:%d%n", &n, &k, &h, &used) == 3) {
+        table.push_back(n); table.push_back(k); table.push_back(h);
+        e += used;
+        if (*e == ',') ++e;
+      } else {
+        break;
+      }
+    }
+  }
+  for (size_t i = 0; i + 2 < table.size(); i += 3)
+    if (table[i] == N && table[i + 1] == K) return table[i + 2];
+  return 0;
+}
+
 static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   const bool cin32 = (g.Cin % 32 == 0);
   if (g.tile_hint == 0) g.tile_hint = env_tile_hint();
+  if (const int o = env_tile_override(g.N, g.K)) g.tile_hint = o;
   {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("MILAN_ABLATE"); dbg = e ? atoi(e) : 0; }
@@ -1039,6 +1065,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     // (chunk size, world size).  Short M just leaves tile rows masked.
     if (g.tile_hint == 3) return launch_split16<256, 256, 4>(g, s);
     if (g.tile_hint == 4) return launch_split16<256, 128, 3>(g, s);
+    if (g.tile_hint == 5) return launch_split16<128, 256, 3>(g, s);
     if (g.tile_hint == 1) return launch_cfg<256, 128, 3, true, true>(g, s);
     if (g.tile_hint == 2) return launch_cfg<128, 128, 2, true, true>(g, s);
     if (g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);

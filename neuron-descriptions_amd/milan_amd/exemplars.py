@@ -1,0 +1,616 @@
+"""Exemplar computation on MI355X: the writer of `images.npy` / `masks.npy`.
+
+Mirror of the reference's `src/exemplars/compute.py` (`compute` :27-246,
+`discriminative` :263-353, `generative` :356-437) -- same function names,
+arguments, output files (`images.npy`, `masks.npy`, `units.npy`, `ids.csv`,
+`activations.csv`) and `ValueError`s -- with the netdissect machinery it calls
+(`RunningTopK`, `RunningQuantile`, `ImageVisualizer`, vendored under
+`src/deps/netdissect`) replaced by the HIP kernels of `csrc/exemplars.hip`.
+
+What stays torch: the dissected model itself (the reference takes it as two
+black-box callables) and the `DataLoader`s.  What stays host Python, as in the
+reference: the control flow of the KLL quantile sketch -- which level is
+compacted when and with which random bit.  The bits come from torch's global
+generator in the reference's order, so a seeded run reproduces the reference's
+quantile levels bit for bit even in the sketch's randomised regime.
+There is no CPU fallback: without the library / a GPU everything here raises.
+"""
+import ctypes
+import math
+import pathlib
+import shutil
+from typing import Any, Callable, Dict, Optional, Sequence, Tuple, Union
+
+import numpy
+import torch
+from torch import nn
+from torch.utils import data
+
+from milan_amd import hip
+
+PathLike = Union[str, pathlib.Path]
+
+
+# ---------------------------------------------------------------------------
+# transforms (src/exemplars/transforms.py)
+# ---------------------------------------------------------------------------
+def map_location(items: Sequence[Any], device) -> Tuple[Any, ...]:
+    return tuple(item.to(device) if isinstance(item, torch.Tensor) and
+                 device is not None else item for item in items)
+
+
+def first(*inputs: Any) -> Tuple[Any, ...]:
+    return (inputs[0],)
+
+
+def identity(inputs):
+    return inputs
+
+
+def identities(*inputs):
+    return inputs
+
+
+def spatialize_vit_mlp(hiddens: torch.Tensor) -> torch.Tensor:
+    """transforms.py:56-81: (batch, patches, units) -> (batch, units, s, s)."""
+    batch_size, n_patches, n_units = hiddens.shape
+    hiddens = hiddens[:, 1:]
+    size = math.isqrt(n_patches - 1)
+    assert size**2 == n_patches - 1
+    return hiddens.permute(0, 2, 1).reshape(batch_size, n_units, size, size)
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _as_hiddens(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# RunningTopK (src/deps/netdissect/runningstats.py:31-151)
+# ---------------------------------------------------------------------------
+class RunningTopK:
+    """Per-unit k largest values + their dataset indices, on the GPU."""
+
+    def __init__(self, k: int = 100, device=None):
+        self.k, self.count = k, 0
+        self.device = device
+        self.values: Optional[torch.Tensor] = None
+        self.index: Optional[torch.Tensor] = None
+        self.filled = 0
+        self.lib = hip.load_library()
+
+    def size(self) -> int:
+        return self.count
+
+    def add_hiddens(self, hiddens: torch.Tensor,
+                    units: Optional[torch.Tensor] = None) -> None:
+        """`hiddens` (batch, channels, *spatial): spatial max per unit
+        (compute.py:331) merged into the running top-k."""
+        hiddens = _as_hiddens(hiddens)
+        device = hip.require_device(hiddens.device)
+        batch, channels = hiddens.shape[:2]
+        hw = int(numpy.prod(hiddens.shape[2:])) if hiddens.dim() > 2 else 1
+        n_units = channels if units is None else len(units)
+        if self.values is None:
+            self.device = device
+            self.values = torch.zeros(n_units, self.k, device=device)
+            self.index = torch.zeros(n_units, self.k, dtype=torch.long,
+                                     device=device)
+        # the merge sorts filled + batch <= 2048 candidates in LDS
+        step = max(1, 2048 - self.k)
+        for lo in range(0, batch, step):
+            part = hiddens[lo:lo + step]
+            scratch = torch.empty(n_units * len(part), device=device)
+            with torch.cuda.device(device):
+                hip._check(self.lib.milan_exemplar_topk_update(
+                    part.data_ptr(), len(part), channels, hw, hip._ptr(units),
+                    n_units, self.count + lo, self.k, self.filled,
+                    scratch.data_ptr(), self.values.data_ptr(),
+                    self.index.data_ptr(), _stream(device)))
+            self.filled = min(self.k, self.filled + len(part))
+        self.count += batch
+
+    def add(self, data_: torch.Tensor) -> None:
+        """Reference contract: `data_` (observations, units) already pooled."""
+        self.add_hiddens(data_)
+
+    def result(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(values, dataset indices), each (units, min(k, seen)), best first."""
+        return (self.values[:, :self.filled].clone(),
+                self.index[:, :self.filled].clone())
+
+    def to_(self, device) -> None:  # results are read with .result().cpu()
+        pass
+
+
+# ---------------------------------------------------------------------------
+# RunningQuantile (src/deps/netdissect/runningstats.py:274-627)
+# ---------------------------------------------------------------------------
+class RunningQuantile:
+    """The KLL sketch with the reference's state machine; tensors on the GPU."""
+
+    def __init__(self, r: int = 3 * 1024, buffersize: Optional[int] = None):
+        self.depth = None
+        self.device = None
+        self.resolution = r * 2
+        if buffersize is None:
+            buffersize = min(128, (self.resolution + 7) // 8)
+        self.buffersize = buffersize
+        self.samplerate = 1.0
+        self.data = None
+        self.firstfree = [0]
+        self.randbits = torch.ByteTensor(self.resolution)
+        self.currentbit = len(self.randbits) - 1
+        self.extremes = None
+        self.count = 0
+        self.batchcount = 0
+        self._ws = None
+        self.lib = hip.load_library()
+
+    def size(self) -> int:
+        return self.count
+
+    # -- plumbing ------------------------------------------------------------
+    def _lazy_init(self, depth: int, device) -> None:
+        self.depth, self.device = depth, hip.require_device(device)
+        self.data = [torch.zeros(depth, self.resolution, device=self.device)]
+        self.extremes = torch.zeros(depth, 2, device=self.device)
+        self.extremes[:, 0] = float('inf')
+        self.extremes[:, 1] = -float('inf')
+
+    def _workspace(self, n: int, pairs: bool) -> torch.Tensor:
+        need = int(self.lib.milan_exemplar_sort_workspace(self.depth, n,
+                                                          int(pairs)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _compact(self, src, n, offset, dst, position, extremes: bool) -> int:
+        """sort src[:, :n]; dst[:, position:] = sorted[:, offset::2]."""
+        ws = self._workspace(n, False)
+        with torch.cuda.device(self.device):
+            hip._check(self.lib.milan_exemplar_sketch_compact(
+                src.data_ptr(), src.shape[1], n, self.depth, offset,
+                dst.data_ptr(), dst.shape[1], position,
+                self.extremes.data_ptr() if extremes else None, ws.data_ptr(),
+                ws.numel(), _stream(self.device)))
+        return (n - offset + 1) // 2
+
+    # -- the reference's state machine ------------------------------------------
+    def add_hiddens(self, hiddens: torch.Tensor,
+                    units: Optional[torch.Tensor] = None) -> None:
+        """Every spatial position of `hiddens` (batch, channels, *spatial) is
+        one sample per unit (compute.py:329-330)."""
+        hiddens = _as_hiddens(hiddens)
+        batch, channels = hiddens.shape[:2]
+        hw = int(numpy.prod(hiddens.shape[2:])) if hiddens.dim() > 2 else 1
+        depth = channels if units is None else len(units)
+        if self.depth is None:
+            self._lazy_init(depth, hiddens.device)
+        assert depth == self.depth, (depth, self.depth)
+        supplied = batch * hw
+        self.count += supplied
+        self.batchcount += 1
+        if self.samplerate < 1.0:
+            raise NotImplementedError(
+                'RunningQuantile subsampling regime (reached after ~1e10 '
+                'samples per unit) is not built')
+        index = 0
+        while index < supplied:  # runningstats.py:363-385
+            ff = self.firstfree[0]
+            available = self.data[0].shape[1] - ff
+            if available == 0:
+                if not self._shift():
+                    raise NotImplementedError(
+                        'RunningQuantile subsampling regime is not built')
+                ff = self.firstfree[0]
+                available = self.data[0].shape[1] - ff
+            copycount = min(available, supplied - index)
+            with torch.cuda.device(self.device):
+                hip._check(self.lib.milan_exemplar_sketch_append(
+                    hiddens.data_ptr(), batch, channels, hw, hip._ptr(units),
+                    self.depth, index, copycount, self.data[0].data_ptr(),
+                    self.data[0].shape[1], ff, _stream(self.device)))
+            self.firstfree[0] += copycount
+            index += copycount
+
+    def add(self, incoming: torch.Tensor) -> None:
+        """Reference contract: `incoming` (samples, units)."""
+        assert incoming.dim() == 2
+        self.add_hiddens(incoming)
+
+    def _randbit(self) -> int:
+        self.currentbit += 1
+        if self.currentbit >= len(self.randbits):
+            self.randbits.random_(to=2)  # torch's global generator, as upstream
+            self.currentbit = 0
+        return int(self.randbits[self.currentbit])
+
+    def _shift(self) -> bool:  # runningstats.py:387-407
+        index = 0
+        while self.data[index].shape[1] - self.firstfree[index] < (
+                -(-self.data[index - 1].shape[1] // 2) if index else 1):
+            if index + 1 >= len(self.data):
+                return self._expand()
+            n = self.firstfree[index]
+            offset = self._randbit()
+            position = self.firstfree[index + 1]
+            moved = self._compact(self.data[index], n, offset,
+                                  self.data[index + 1], position,
+                                  extremes=(index == 0 and
+                                            self.samplerate >= 1.0))
+            self.firstfree[index] = 0
+            self.firstfree[index + 1] += moved
+            index += 1
+        return True
+
+    def _next_capacity(self) -> int:  # :523-529
+        cap = int(math.ceil(self.resolution * (0.67**len(self.data))))
+        if cap < 2:
+            return 0
+        cap = -8 * (-cap // 8)
+        return max(self.buffersize, cap)
+
+    def _expand(self) -> bool:  # :485-521
+        cap = self._next_capacity()
+        if cap > 0:
+            self.data.insert(0, torch.zeros(self.depth, cap,
+                                            device=self.device))
+            self.firstfree.insert(0, 0)
+        else:
+            assert self.firstfree[0] == 0
+            self.samplerate *= 0.5
+        for index in range(1, len(self.data)):
+            amount = self.firstfree[index]
+            if amount == 0:
+                continue
+            position = self.firstfree[index - 1]
+            if self.data[index - 1].shape[1] - (amount + position) >= (
+                    -(-self.data[index - 2].shape[1] // 2) if
+                (index - 1) else 1):
+                self.data[index - 1][:, position:position + amount] = (
+                    self.data[index][:, :amount])
+                self.firstfree[index - 1] += amount
+                self.firstfree[index] = 0
+            else:
+                offset = self._randbit()
+                self.firstfree[index] = self._compact(
+                    self.data[index], amount, offset, self.data[index], 0,
+                    extremes=(index == 1))
+        return cap > 0
+
+    def quantiles(self, quantile: float) -> torch.Tensor:
+        """`quantiles(q)` for a scalar q -> (units,) float32 (:557-580)."""
+        if self.count == 0:
+            return torch.full((self.depth or 0,), float('nan'))
+        total = sum(self.firstfree)
+        ws = self._workspace(total, True)
+        n = len(self.data)
+        ptrs = (ctypes.c_void_p * n)(*[d.data_ptr() for d in self.data])
+        ff = (ctypes.c_int64 * n)(*self.firstfree)
+        caps = (ctypes.c_int64 * n)(*[d.shape[1] for d in self.data])
+        out = torch.empty(self.depth, device=self.device)
+        q32 = float(torch.tensor(quantile, dtype=torch.float32))
+        with torch.cuda.device(self.device):
+            hip._check(self.lib.milan_exemplar_sketch_quantile(
+                ptrs, ff, caps, n, self.depth, self.extremes.data_ptr(), q32,
+                out.data_ptr(), ws.data_ptr(), ws.numel(),
+                _stream(self.device)))
+        return out
+
+    def to_(self, device) -> None:
+        pass
+
+
+# ---------------------------------------------------------------------------
+# ImageVisualizer pieces
+# ---------------------------------------------------------------------------
+def _find(source, predicate):
+    """Crawl dataset.transform / .transforms like netdissect does."""
+    if source is None:
+        return None
+    if predicate(source):
+        return source
+    found = _find(getattr(source, 'transform', None), predicate)
+    if found is not None:
+        return found
+    for t in reversed(getattr(source, 'transforms', None) or []):
+        found = _find(t, predicate)
+        if found is not None:
+            return found
+    return None
+
+
+def byte_renormalization(source=None) -> Tuple[numpy.ndarray, numpy.ndarray]:
+    """(mul, add) of `renormalize.renormalizer(source=..., target='byte')`
+    (src/deps/netdissect/renormalize.py:55-136): undo the dataset's Normalize
+    (anything with `.mean` / `.std`, else images are taken to be in [0, 1])
+    and scale to 0..255.  float64 like the reference; cast to float32 at use."""
+    normalizer = _find(source, lambda t: hasattr(t, 'mean') and
+                       hasattr(t, 'std') and not isinstance(t, torch.Tensor))
+    if normalizer is not None:
+        oldoffset, oldscale = normalizer.mean, normalizer.std
+    else:
+        oldoffset, oldscale = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    newscale = numpy.array([1.0 / 255] * 3)
+    mul = numpy.array(oldscale, dtype=numpy.float64) / newscale
+    add = (numpy.array(oldoffset, dtype=numpy.float64) - 0.0) / newscale
+    return mul, add
+
+
+class _Cells:
+    """Output arrays of `individual_masked_images_for_topk`, on the GPU."""
+
+    def __init__(self, n_units, k, size, device):
+        self.k, self.size, self.device = k, size, device
+        self.images = torch.zeros(n_units, k, 3, size, size, dtype=torch.uint8,
+                                  device=device)
+        self.masks = torch.zeros(n_units, k, 1, size, size, dtype=torch.uint8,
+                                 device=device)
+        self.masked = torch.zeros(n_units, k, 3, size, size, dtype=torch.uint8,
+                                  device=device)
+
+    def render(self, lib, activations, images, cells, levels, mul, add):
+        activations = _as_hiddens(activations)
+        images = _as_hiddens(images)
+        assert activations.dim() == 4 and images.dim() == 4
+        batch, channels, h, w = activations.shape
+        cells_dev = torch.tensor(cells, dtype=torch.int32,
+                                 device=self.device).reshape(-1, 4)
+        mul3 = (ctypes.c_float * 3)(*[float(numpy.float32(v)) for v in mul])
+        add3 = (ctypes.c_float * 3)(*[float(numpy.float32(v)) for v in add])
+        with torch.cuda.device(self.device):
+            hip._check(lib.milan_exemplar_render(
+                activations.data_ptr(), batch, channels, h, w,
+                images.data_ptr(), images.shape[2], images.shape[3],
+                cells_dev.data_ptr(), len(cells_dev), levels.data_ptr(), mul3,
+                add3, self.size, self.k, self.images.data_ptr(),
+                self.masks.data_ptr(), self.masked.data_ptr(),
+                _stream(self.device)))
+
+
+# ---------------------------------------------------------------------------
+# compute / discriminative / generative
+# ---------------------------------------------------------------------------
+ActivationStats = Tuple[RunningTopK, RunningQuantile]
+
+
+def compute(compute_topk_and_quantile: Callable[..., Any],
+            compute_activations: Callable[..., Any],
+            dataset: data.Dataset,
+            units: Optional[Sequence[int]] = None,
+            k: int = 15,
+            quantile: float = 0.99,
+            output_size: int = 224,
+            batch_size: int = 128,
+            image_size: Optional[int] = None,
+            renormalizer=None,
+            num_workers: int = 30,
+            results_dir: Optional[PathLike] = None,
+            viz_dir: Optional[PathLike] = None,
+            tally_cache_file: Optional[PathLike] = None,
+            masks_cache_file: Optional[PathLike] = None,
+            save_results: bool = True,
+            save_viz: bool = True,
+            clear_cache_files: bool = False,
+            clear_results_dir: bool = False,
+            clear_viz_dir: bool = False,
+            display_progress: bool = True) -> ActivationStats:
+    """Find the top-activating images of each unit and their masks
+    (reference compute.py:27-246; same arguments).
+
+    `compute_topk_and_quantile(*batch)` returns either the reference's pair
+    (pooled (batch, units), activations (samples, units)) or -- cheaper, no
+    permuted copy -- the hidden tensor (batch, units, h, w) itself;
+    `compute_activations(*batch)` returns hiddens (batch, units, h, w) or
+    (hiddens, images).  The netdissect caches (`*_cache_file`) are accepted and
+    ignored: the tally is not the slow part here.
+    """
+    if units is not None and not units:
+        raise ValueError('when setting `units`, must provide >= 1 unit')
+    if k < 1:
+        raise ValueError(f'must have k >= 1, got k={k}')
+    if quantile <= 0 or quantile >= 1:
+        raise ValueError('must have quantile in range (0, 1), '
+                         f'got quantile={quantile}')
+    if image_size is None and not hasattr(dataset, 'transform'):
+        raise ValueError('dataset has no `transform` property so '
+                         'image_size= must be set')
+    del tally_cache_file, masks_cache_file, clear_cache_files
+    del display_progress, image_size
+    lib = hip.load_library()
+
+    if results_dir is None:
+        import os
+        results_dir = pathlib.Path(os.environ.get('MILAN_RESULTS_DIR',
+                                                  'results')) / 'exemplars'
+    results_dir = pathlib.Path(results_dir)
+    viz_dir = pathlib.Path(viz_dir) if viz_dir is not None else \
+        results_dir / 'viz'
+    for save, clear, directory in ((save_results, clear_results_dir,
+                                    results_dir),
+                                   (save_viz, clear_viz_dir, viz_dir)):
+        if not save:
+            continue
+        if clear and directory.exists():
+            shutil.rmtree(directory)
+        directory.mkdir(exist_ok=True, parents=True)
+
+    units_dev = None
+    if units is not None:
+        units = sorted(units)
+        if save_results:
+            numpy.save(f'{results_dir}/units.npy', numpy.array(units))
+
+    # ---- pass 1: tally (tally.tally_topk_and_quantile, tally.py:199-222) ----
+    topk, rq = RunningTopK(k=k), RunningQuantile(r=4096)
+    loader = data.DataLoader(dataset, batch_size=batch_size,
+                             num_workers=num_workers)
+    for batch in loader:
+        batch = batch if isinstance(batch, (list, tuple)) else [batch]
+        outputs = compute_topk_and_quantile(*batch)
+        if isinstance(outputs, torch.Tensor):
+            pooled, samples = outputs, outputs  # hiddens (b, c, h, w)
+        else:
+            pooled, samples = outputs
+        if units is not None and units_dev is None:
+            units_dev = torch.tensor(units, dtype=torch.int32,
+                                     device=pooled.device)
+        topk.add_hiddens(pooled, units_dev)
+        rq.add_hiddens(samples, units_dev)
+
+    if not (save_results or save_viz):
+        return topk, rq
+
+    # ---- pass 2: render the top images (imgviz.py / tally.gather_topk) --------
+    levels = rq.quantiles(quantile).reshape(-1)
+    mul, add = byte_renormalization(renormalizer if renormalizer is not None
+                                    else dataset)
+    _, ids = topk.result()
+    ids_host = ids.cpu()
+    n_units = ids_host.shape[0]
+    cells = _Cells(n_units, k, output_size, topk.device)
+    needed: Dict[int, list] = {}
+    for unit in range(n_units):
+        for rank, imgnum in enumerate(ids_host[unit].tolist()):
+            needed.setdefault(imgnum, []).append((unit, rank))
+    order = sorted(needed)
+    loader = data.DataLoader(dataset, sampler=order, batch_size=batch_size,
+                             num_workers=num_workers)
+    seen = 0
+    for batch in loader:
+        batch = batch if isinstance(batch, (list, tuple)) else [batch]
+        outputs = compute_activations(*batch)
+        if isinstance(outputs, torch.Tensor):
+            activations, images = outputs, batch[0]
+        else:
+            activations, images = outputs
+        todo = []
+        for j in range(len(activations)):
+            for unit, rank in needed[order[seen + j]]:
+                channel = unit if units is None else units[unit]
+                todo += [j, channel, unit, rank]
+        cells.render(lib, activations, images.to(activations.device), todo,
+                     levels, mul, add)
+        seen += len(activations)
+
+    if save_results:
+        numpy.save(f'{results_dir}/images.npy', cells.images.cpu().numpy())
+        numpy.save(f'{results_dir}/masks.npy', cells.masks.cpu().numpy())
+        activations, ids = topk.result()
+        for metadata, name, fmt in ((activations, 'activations', '%.5e'),
+                                    (ids, 'ids', '%i')):
+            metadata = metadata.view(n_units, -1).cpu().numpy()
+            numpy.savetxt(str(results_dir / f'{name}.csv'), metadata,
+                          delimiter=',', fmt=fmt)
+    if save_viz:
+        try:
+            from PIL import Image
+        except ImportError as error:  # pragma: no cover
+            raise RuntimeError('save_viz=True needs PIL') from error
+        masked = cells.masked.permute(0, 1, 3, 4, 2).cpu().numpy()
+        for unit in range(n_units):
+            unit_dir = viz_dir / f'unit_{unit}'
+            unit_dir.mkdir(exist_ok=True, parents=True)
+            for rank in range(masked.shape[1]):
+                Image.fromarray(masked[unit, rank]).save(
+                    unit_dir / f'image_{rank}.png')
+    topk.cells = cells  # the rendered arrays, for callers that skip the files
+    return topk, rq
+
+
+def _run_model(model: nn.Module, inputs) -> Any:
+    if not isinstance(inputs, (tuple, dict)):
+        raise ValueError(f'inputs must be a tuple or dict, got {type(inputs)}')
+    return model(**inputs) if isinstance(inputs, dict) else model(*inputs)
+
+
+class _Retain:
+    """Forward hook standing in for nethook.InstrumentedModel.retain_layer."""
+
+    def __init__(self, model: nn.Module, layer: Optional[str]):
+        self.output = None
+        self.handle = None
+        if layer is not None:
+            modules = dict(model.named_modules())
+            if layer not in modules:
+                raise KeyError(f'layer not found: {layer}')
+            self.handle = modules[layer].register_forward_hook(
+                lambda _m, _i, out: setattr(self, 'output', out))
+
+    def close(self):
+        if self.handle is not None:
+            self.handle.remove()
+
+
+def discriminative(model: nn.Module,
+                   dataset: data.Dataset,
+                   layer: Optional[Union[str, int]] = None,
+                   device=None,
+                   results_dir: Optional[PathLike] = None,
+                   viz_dir: Optional[PathLike] = None,
+                   transform_inputs=first,
+                   transform_hiddens=identity,
+                   **kwargs: Any) -> ActivationStats:
+    """Exemplars of a model whose inputs are the images (compute.py:263-353)."""
+    device = hip.require_device(device or 'cuda')
+    model.to(device)
+
+    def resolve(directory):
+        if directory is not None:
+            directory = pathlib.Path(directory)
+            directory /= str(layer) if layer is not None else 'outputs'
+        return directory
+
+    layer = str(layer) if layer is not None else None
+    hook = _Retain(model, layer)
+
+    def hiddens(*args):
+        inputs = transform_inputs(*map_location(args, device))
+        with torch.no_grad():
+            outputs = _run_model(model, inputs)
+        return transform_hiddens(outputs if layer is None else hook.output)
+
+    try:
+        return compute(hiddens, hiddens, dataset,
+                       results_dir=resolve(results_dir),
+                       viz_dir=resolve(viz_dir), **kwargs)
+    finally:
+        hook.close()
+
+
+def generative(model: nn.Module,
+               dataset: data.Dataset,
+               layer: Union[str, int],
+               device=None,
+               results_dir: Optional[PathLike] = None,
+               viz_dir: Optional[PathLike] = None,
+               transform_inputs=identities,
+               transform_hiddens=identity,
+               transform_outputs=identity,
+               **kwargs: Any) -> ActivationStats:
+    """Exemplars of a generator: the images are its outputs
+    (compute.py:356-437)."""
+    device = hip.require_device(device or 'cuda')
+    if results_dir is not None:
+        results_dir = pathlib.Path(results_dir) / str(layer)
+    if viz_dir is not None:
+        viz_dir = pathlib.Path(viz_dir) / str(layer)
+    model.to(device)
+    hook = _Retain(model, str(layer))
+
+    def run(*args):
+        inputs = transform_inputs(*map_location(args, device))
+        with torch.no_grad():
+            images = _run_model(model, inputs)
+        return transform_hiddens(hook.output), transform_outputs(images)
+
+    try:
+        return compute(lambda *a: run(*a)[0], run, dataset,
+                       results_dir=results_dir, viz_dir=viz_dir, **kwargs)
+    finally:
+        hook.close()

@@ -50,7 +50,7 @@ class Dims(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 3  # MILAN_ABI_VERSION this binding was written against
+ABI_VERSION = 4  # MILAN_ABI_VERSION this binding was written against
 
 # milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
 TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET, TRUNK_NONE = 0, 1, 2, 3
@@ -61,6 +61,7 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
 _SZ = ctypes.c_size_t
+_I64 = ctypes.c_int64
 
 # name -> (restype, argtypes); must list every symbol include/milan_hip.h
 # declares (tests/test_host.py checks the two against each other).
@@ -105,6 +106,19 @@ SIGNATURES = {
         ctypes.POINTER(ctypes.c_longlong)
     ]),
     'milan_profile_read_stages': (_I, [ctypes.POINTER(ctypes.c_double)]),
+    'milan_exemplar_topk_update':
+        (_I, [_P, _I, _I, _I, _P, _I, _I64, _I, _I, _P, _P, _P, _P]),
+    'milan_exemplar_sketch_append':
+        (_I, [_P, _I, _I, _I, _P, _I, _I64, _I64, _P, _I64, _I64, _P]),
+    'milan_exemplar_sort_workspace': (_SZ, [_I, _I64, _I]),
+    'milan_exemplar_sketch_compact':
+        (_I, [_P, _I64, _I64, _I, _I, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    'milan_exemplar_sketch_quantile':
+        (_I, [ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+              _I, _I, _P, _F, _P, _P, _SZ, _P]),
+    'milan_exemplar_render':
+        (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P,
+              ctypes.POINTER(_F), ctypes.POINTER(_F), _I, _I, _P, _P, _P, _P]),
     'milan_conv2d_nhwc':
         (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I,
               _P]),

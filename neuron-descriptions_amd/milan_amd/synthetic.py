@@ -303,3 +303,39 @@ def exemplars(n_neurons: int,
 def describe(sd: Dict[str, torch.Tensor]) -> Sequence[str]:
     """Human-readable `name shape` lines (used by docs/tests)."""
     return [f'{k} {tuple(v.shape)}' for k, v in sd.items()]
+
+
+# ---------------------------------------------------------------------------
+# exemplar computation (src/exemplars/compute.py): tiny dissected models
+# ---------------------------------------------------------------------------
+def exemplar_model(n_units: int = 3,
+                   n_layers: int = 2,
+                   seed: int = 0,
+                   kernel_size: int = 4,
+                   padding: int = 2,
+                   relu: bool = False) -> 'torch.nn.Sequential':
+    """The reference's test model (`tests/exemplars/compute_test.py:47-63`):
+    conv_1 (3 -> units) and conv_i (units -> units), kernel 4, padding 2 --
+    with weights drawn from a seeded generator so that every box rebuilds the
+    same model.  `relu=True` appends a ReLU to every layer's output (ties at
+    zero, as in real post-ReLU feature maps)."""
+    import collections
+
+    from torch import nn
+    g = _gen(seed)
+    layers = []
+    for index in range(1, n_layers + 1):
+        cin = 3 if index == 1 else n_units
+        conv = nn.Conv2d(cin, n_units, kernel_size, padding=padding)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) *
+                              (1.0 / (cin * kernel_size**2))**0.5)
+            conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.1)
+        layers.append((f'conv_{index}',
+                       nn.Sequential(conv, nn.ReLU()) if relu else conv))
+    return nn.Sequential(collections.OrderedDict(layers)).eval()
+
+
+def exemplar_images(n_images: int, size: int = 16, seed: int = 0) -> torch.Tensor:
+    """`tests/conftest.py:28-31`: a TensorDataset of rand(n, 3, size, size)."""
+    return torch.rand(n_images, 3, size, size, generator=_gen(seed))

@@ -1,0 +1,164 @@
+"""GPU: the exemplar-computation kernels (csrc/exemplars.hip, through the C ABI
+and the `milan_amd.exemplars` mirror of src/exemplars/compute.py) against
+goldens G15 -- the reference's own `discriminative` / `generative` -- and
+against the CPU oracle on larger random cases.
+
+Bar: `images.npy` / `masks.npy` / masked visualisations bit-exact uint8, top-k
+ids and activations identical, quantile levels identical (float32), including
+the randomised KLL regime under the same torch seed.  To compare the KERNELS
+and not two convolution libraries, the dissected model runs on the CPU in these
+tests (as it did when the goldens were made) and its activations are handed to
+the GPU; one end-to-end test runs the model on the GPU too."""
+import collections
+import json
+
+import numpy
+import pytest
+import torch
+from torch import nn
+from torch.utils import data
+
+from conftest import GOLDEN_DIR
+from milan_amd import exemplars, hip, synthetic
+from oracle import exemplars_oracle as E
+from test_exemplar_goldens import CASES, FeaturesToImage, build, check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def G():
+    return torch.load(GOLDEN_DIR / 'reference_goldens_exemplars.pt')
+
+
+@pytest.fixture(scope='module')
+def M():
+    with open(GOLDEN_DIR / 'reference_goldens_exemplars.json') as f:
+        return json.load(f)
+
+
+def cpu_model_callbacks(model, layer, generative=False):
+    """The model on the CPU (bit-identical activations to the reference's
+    run), activations shipped to the GPU."""
+
+    def run(images):
+        x, hid = images.cpu(), None
+        with torch.no_grad():
+            for name, child in model.named_children():
+                x = child(x)
+                if name == layer:
+                    hid = x
+                    if not generative:
+                        break
+        hid = x if hid is None else hid
+        return hid.cuda(), x.cuda()
+
+    if generative:
+        return (lambda images: run(images)[0]), run
+    return (lambda images: run(images)[0]), (lambda images: run(images)[0])
+
+
+def run_case(case, tmp_path, reference_contract=False):
+    model, dataset = build(case)
+    call = dict(case['call'])
+    layer = call.pop('layer')
+    tally, acts = cpu_model_callbacks(model, layer,
+                                      bool(case.get('generative')))
+    if reference_contract:
+        # the reference's callback contract: (pooled, activations (N, C))
+        def tally(images, _inner=tally):  # noqa: E306
+            h = _inner(images)
+            b, c = h.shape[:2]
+            return (h.view(b, c, -1).max(dim=2)[0],
+                    h.permute(0, 2, 3, 1).reshape(-1, c))
+    torch.manual_seed(case['rng'])
+    topk, rq = exemplars.compute(tally, acts, dataset, results_dir=tmp_path,
+                                 image_size=case['images'][1],
+                                 num_workers=0, save_viz=False,
+                                 display_progress=False, **call)
+    values, ids = topk.result()
+    got = dict(images=torch.from_numpy(numpy.load(tmp_path / 'images.npy')),
+               masks=torch.from_numpy(numpy.load(tmp_path / 'masks.npy')),
+               masked=topk.cells.masked.cpu(), ids=ids.cpu(),
+               activations=values.cpu(),
+               levels=rq.quantiles(call['quantile']).cpu())
+    return got, topk, rq
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_kernels_match_reference_exemplars(G, M, name, tmp_path):
+    hip.require_device('cuda')
+    got, topk, rq = run_case(M[name], tmp_path)
+    check(got, G, name)
+    assert rq.firstfree == M[name]['sketch']['firstfree']
+    assert [d.shape[1] for d in rq.data] == M[name]['sketch']['sizes']
+    assert rq.count == M[name]['sketch']['count']
+    # the files the reference writes
+    ids_csv = numpy.loadtxt(tmp_path / 'ids.csv', delimiter=',',
+                            dtype=numpy.int64, ndmin=2)
+    assert (ids_csv == G[f'{name}_ids'].numpy()).all()
+    assert (tmp_path / 'activations.csv').read_text() == \
+        M[name]['activations_csv']
+    if 'units' in M[name]['call']:
+        assert numpy.load(tmp_path / 'units.npy').tolist() == sorted(
+            M[name]['call']['units'])
+
+
+@pytest.mark.parametrize('name', ['layer_q90', 'kll'])
+def test_reference_callback_contract(G, M, name, tmp_path):
+    """`compute` also takes the reference's (pooled, activations) pair."""
+    got, _, _ = run_case(M[name], tmp_path, reference_contract=True)
+    check(got, G, name)
+
+
+@pytest.mark.parametrize('seed,units,n,size,k,batch,out', [
+    (1, 64, 300, 24, 15, 32, 56),   # 300 x 26 x 26 samples: deep KLL regime
+    (2, 33, 70, 16, 9, 128, 224),   # one batch, production output size
+    (3, 8, 40, 40, 40, 7, 33),      # k == dataset size, ragged batches
+])
+def test_kernels_match_oracle_on_random_cases(seed, units, n, size, k, batch,
+                                              out, tmp_path):
+    hip.require_device('cuda')
+    model = synthetic.exemplar_model(units, 2, seed, relu=True)
+    dataset = data.TensorDataset(synthetic.exemplar_images(n, size, seed + 50))
+    kwargs = dict(k=k, quantile=0.99, output_size=out, batch_size=batch)
+    torch.manual_seed(seed)
+    want = E.discriminative(model, dataset, 'conv_2', **kwargs)
+    tally, acts = cpu_model_callbacks(model, 'conv_2')
+    torch.manual_seed(seed)
+    topk, rq = exemplars.compute(tally, acts, dataset, results_dir=tmp_path,
+                                 image_size=size, num_workers=0,
+                                 save_viz=False, **kwargs)
+    values, ids = topk.result()
+    assert torch.equal(ids.cpu(), want['ids'])
+    assert torch.equal(values.cpu(), want['activations'])
+    assert torch.equal(rq.quantiles(0.99).cpu(), want['levels'])
+    for key in ('images', 'masks', 'masked'):
+        assert torch.equal(getattr(topk.cells, key).cpu(), want[key]), key
+
+
+def test_discriminative_end_to_end_on_gpu(M, G, tmp_path):
+    """The drop-in call with the model on the GPU: same files, same top
+    images; masks may differ only where MIOpen's convolution rounds
+    differently from the CPU's right at the threshold."""
+    case = M['layer_q90']
+    model, dataset = build(case)
+    call = dict(case['call'])
+    layer = call.pop('layer')
+    torch.manual_seed(case['rng'])
+    exemplars.discriminative(model, dataset, layer=layer, device='cuda',
+                             results_dir=tmp_path, viz_dir=tmp_path / 'viz',
+                             image_size=16, num_workers=0, save_viz=True,
+                             **call)
+    out = tmp_path / layer
+    images = torch.from_numpy(numpy.load(out / 'images.npy'))
+    masks = torch.from_numpy(numpy.load(out / 'masks.npy'))
+    assert torch.equal(images, G['layer_q90_images'])
+    assert (masks != G['layer_q90_masks']).float().mean() < 1e-3
+    assert (tmp_path / 'viz' / layer / 'unit_0' / 'image_0.png').is_file()
+    with pytest.raises(ValueError, match='k >= 1'):
+        exemplars.compute(None, None, dataset, k=0, image_size=16)
+    with pytest.raises(ValueError, match='quantile in range'):
+        exemplars.compute(None, None, dataset, quantile=2, image_size=16)
+    with pytest.raises(ValueError, match='image_size= must be set'):
+        exemplars.compute(None, None, dataset)
