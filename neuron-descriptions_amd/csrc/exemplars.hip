@@ -139,6 +139,43 @@ __global__ void sketch_decimate_kernel(const float* __restrict__ sorted,
   }
 }
 
+// Fused compaction for rows of up to 8192 samples (every level of the r = 4096
+// sketch the reference's tally builds): one workgroup per unit sorts its row in
+// LDS (bitonic, 32 KB), writes every second element from `offset` on to dst and
+// folds the row's ends into the extremes.  One launch instead of a copy, a
+// library sort and a gather; dst may alias src (the row is in LDS by then).
+constexpr int kSortCap = 8192;
+__global__ __launch_bounds__(1024) void sketch_sort_decimate_kernel(
+    const float* __restrict__ src, long src_capacity, int n, int offset,
+    float* dst, long dst_capacity, long position, float* __restrict__ extremes) {
+  __shared__ float v[kSortCap];
+  const int u = blockIdx.x, tid = threadIdx.x;
+  int P = 2;
+  while (P < n) P <<= 1;
+  for (int i = tid; i < P; i += 1024)
+    v[i] = i < n ? src[(long)u * src_capacity + i] : INFINITY;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += 1024) {
+        // t-th compare-exchange of this pass: lower index of the pair
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi = lo | stride;
+        const float a = v[lo], b = v[hi];
+        const bool up = (lo & size) == 0;  // ascending run
+        if (up ? (a > b) : (a < b)) { v[lo] = b; v[hi] = a; }
+      }
+      __syncthreads();
+    }
+  const int m = (n - offset + 1) / 2;
+  for (int j = tid; j < m; j += 1024)
+    dst[(long)u * dst_capacity + position + j] = v[offset + 2 * j];
+  if (extremes && tid == 0) {
+    extremes[2 * u] = fminf(extremes[2 * u], v[0]);
+    extremes[2 * u + 1] = fmaxf(extremes[2 * u + 1], v[n - 1]);
+  }
+}
+
 // min / max of the first n columns of every row (runningstats.py:409-413)
 __global__ __launch_bounds__(256) void sketch_scan_extremes_kernel(
     const float* __restrict__ level, long capacity, long n,
@@ -386,16 +423,23 @@ int milan_exemplar_sketch_compact(const float* src, int64_t src_capacity,
                                   int64_t dst_capacity, int64_t position,
                                   float* extremes, void* workspace,
                                   size_t workspace_bytes, milan_stream stream) {
-  MILAN_REQUIRE(src && dst && workspace, MILAN_ERR_ARG,
+  MILAN_REQUIRE(src && dst && (workspace || n <= 8192), MILAN_ERR_ARG,
                 "sketch_compact: null argument");
   MILAN_REQUIRE(n > 0 && n <= src_capacity && n_units > 0 &&
                     (offset == 0 || offset == 1) && position >= 0 &&
                     position + (n - offset + 1) / 2 <= dst_capacity &&
                     (int64_t)n_units * n < (int64_t)1 << 31,
                 MILAN_ERR_SHAPE, "sketch_compact: bad geometry");
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= kSortCap) {  // every level of the reference's r = 4096 sketch
+    hipLaunchKernelGGL(sketch_sort_decimate_kernel, dim3(n_units), dim3(1024), 0,
+                       s, src, (long)src_capacity, (int)n, offset, dst,
+                       (long)dst_capacity, (long)position, extremes);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   MILAN_REQUIRE(workspace_bytes >= milan_exemplar_sort_workspace(n_units, n, 0),
                 MILAN_ERR_WORKSPACE, "sketch_compact: workspace too small");
-  hipStream_t s = (hipStream_t)stream;
   char* w = (char*)workspace;
   int* begin = (int*)w; w += align256(sizeof(int) * (size_t)n_units);
   int* end = (int*)w; w += align256(sizeof(int) * (size_t)n_units);

@@ -171,13 +171,15 @@ class RunningQuantile:
 
     def _compact(self, src, n, offset, dst, position, extremes: bool) -> int:
         """sort src[:, :n]; dst[:, position:] = sorted[:, offset::2]."""
-        ws = self._workspace(n, False)
+        # rows of <= 8192 samples are sorted in LDS by one fused kernel; only
+        # a sketch built with r > 4096 needs the library sort's workspace
+        ws = self._workspace(n, False) if n > 8192 else None
         with torch.cuda.device(self.device):
             hip._check(self.lib.milan_exemplar_sketch_compact(
                 src.data_ptr(), src.shape[1], n, self.depth, offset,
                 dst.data_ptr(), dst.shape[1], position,
-                self.extremes.data_ptr() if extremes else None, ws.data_ptr(),
-                ws.numel(), _stream(self.device)))
+                self.extremes.data_ptr() if extremes else None, hip._ptr(ws),
+                0 if ws is None else ws.numel(), _stream(self.device)))
         return (n - offset + 1) // 2
 
     # -- the reference's state machine ------------------------------------------
