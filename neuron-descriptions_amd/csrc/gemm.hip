@@ -1053,7 +1053,11 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
                     "Cin %% 8 == 0 and N <= 64 (Cin=%d N=%d)", g.Cin, g.N);
       return launch_cfg<256, 64, 2, false, true>(g, s);
     }
-    if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
+    if (g.N <= 64) {
+      if (g.tile_hint == 6) return launch_split16<512, 64, 3>(g, s);
+      if (g.tile_hint == 7) return launch_split16<256, 64, 4>(g, s);
+      return launch_cfg<256, 64, 2, true, true>(g, s);
+    }
     // Measured on the 4096-neuron workload (profiles/): the 4-wave 256x128
     // tile with 16-slot k-tiles, a 3-deep ring and DMA pieces interleaved with
     // the MFMA groups (2 workgroups per CU) is the fastest split-mode
