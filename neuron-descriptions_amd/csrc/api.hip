@@ -163,8 +163,8 @@ int milan_finalize_weights(milan_ctx* c, milan_stream stream) {
   MILAN_CHECK_HIP(hipSetDevice(c->device));
   MILAN_TRY(encoder_finalize(c, s));
   MILAN_TRY(decoder_finalize(c, s));
-  MILAN_REQUIRE(c->stem.w || c->lstm_ih.w, MILAN_ERR_STATE,
-                "no encoder and no decoder weights were uploaded");
+  MILAN_REQUIRE(c->stem.w || c->lstm_ih.w || c->lm_out.w, MILAN_ERR_STATE,
+                "no encoder, decoder or language-model weights were uploaded");
   MILAN_CHECK_HIP(hipStreamSynchronize(s));
   c->raw.clear();
   c->finalized = true;

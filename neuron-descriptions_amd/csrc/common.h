@@ -89,6 +89,9 @@ struct GemmArgs {
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2 };
 
 int launch_gemm(const GemmArgs& g, hipStream_t s);
+// a and b in one launch when both run on the 256x256 split16 kernel (tiles
+// interleaved; see igemm_split16_pair_kernel), otherwise one after the other
+int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 // rows x K fp32 (row stride ld_src) -> split format (row stride ld_dst), x scale
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
                         long rows, int K, float scale, hipStream_t s);

@@ -117,8 +117,11 @@ static int cat_linear(milan_ctx* c, const LinearW& a, const LinearW& b,
   return make_split_weight(c, out->w, out->n, out->kp, &out->ws, &out->ws_inv, s);
 }
 
+static int lm_finalize(milan_ctx* c, hipStream_t s);
+
 int decoder_finalize(milan_ctx* c, hipStream_t s) {
-  if (!find(c, "lstm.weight_ih")) return 0;  // encoder-only context
+  // encoder-only context, or a standalone LanguageModel (lm.* weights only)
+  if (!find(c, "lstm.weight_ih")) return lm_finalize(c, s);
   const milan_dims& d = c->d;
   const int F = d.feature_size, H = d.hidden_size, E = d.embedding_size,
             A = d.attention_size, V = d.vocab_size;
@@ -148,7 +151,16 @@ int decoder_finalize(milan_ctx* c, hipStream_t s) {
     MILAN_TRY(copy_vec(c, b, &c->att_b, s));
     MILAN_TRY(copy_vec(c, e, &c->embedding, s));
   }
-  if (d.has_lm) {
+  return lm_finalize(c, s);
+}
+
+// LanguageModel weights (src/milan/lms.py:47-56): present in a Decoder with an
+// LM, or on their own for a standalone LanguageModel.
+static int lm_finalize(milan_ctx* c, hipStream_t s) {
+  const milan_dims& d = c->d;
+  const int V = d.vocab_size;
+  if (!d.has_lm || !find(c, "lm.lstm.weight_ih_l0")) return 0;
+  {
     const int Hl = d.lm_hidden_size, El = d.lm_embedding_size;
     c->lm_ih.resize(d.lm_layers);
     c->lm_hh.resize(d.lm_layers);

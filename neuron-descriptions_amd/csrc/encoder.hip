@@ -11,6 +11,7 @@
 // 226-235); bn1+relu+maxpool run as one fused kernel.
 #include "common.h"
 #include <optional>
+#include <vector>
 
 #include <cstdlib>
 
@@ -591,16 +592,18 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
     const float* __restrict__ tap, int P, int C, int level, Levels lv,
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
     const int* __restrict__ list_n, float* __restrict__ features, int fstride,
-    int col_off) {
+    int col_off, int img0) {
   __shared__ float part[4][64];
-  const int img = blockIdx.x;
+  // `tap` points at image img0 of the batch; lists / features are indexed by
+  // the absolute image number
+  const int img = blockIdx.x + img0;
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
   const int phase = threadIdx.x >> 6;
   const long base = (long)img * lv.per_image + lv.off[level];
   const int cnt = list_n[img * 5 + level];
   // split format: channel c lives in group c/8 = 32 B [hi x8 | lo x8]
   const long coff = SPLIT_IN ? (long)(c >> 3) * 8 : c;
-  const float* t = tap + (long)img * P * C + coff;
+  const float* t = tap + (long)blockIdx.x * P * C + coff;
   auto fetch = [&](int p) -> float {
     if constexpr (SPLIT_IN) {
       const _Float16* q =
@@ -637,6 +640,7 @@ struct EncPlan {
   Levels lv;
   int h1, w1, hp, wp;
   float *in4, *raw, *x0, *x1, *ds, *t1, *t2;
+  size_t x_sz, t1_sz, t2_sz;  // per-image extents of x0/x1/ds, t1, t2 (floats)
   int *list_idx, *list_n;
   float* list_w;
 };
@@ -671,6 +675,7 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
     t1_sz = t1_sz > in_px * planes ? t1_sz : in_px * planes;   // c1 output
     t2_sz = t2_sz > out_px * planes ? t2_sz : out_px * planes; // c2 output
   }
+  pl->x_sz = x_sz; pl->t1_sz = t1_sz; pl->t2_sz = t2_sz;
   pl->in4 = a.get<float>((size_t)n * H * (W + 2) * 4);
   pl->raw = a.get<float>((size_t)n * pl->h1 * pl->w1 * wd);
   pl->x0 = a.get<float>((size_t)n * x_sz);
@@ -695,6 +700,21 @@ static int encoder_sub_batch() {
     if (v < 1) v = 3840;
   }
   return v;
+}
+
+// MILAN_ENC_PIPELINE=1: two-half software pipeline over the late stages (see
+// encoder_run_batch).  MEASURED in round 2 and kept OFF: bitwise identical
+// results, but layer3 takes 127.5 ms instead of 123.2 per 256-neuron pass -- the
+// expand convs' epilogues already run at the practical HBM rate when every CU
+// is in one (4.75 TB/s), and interleaving a second problem's tiles costs more
+// in L2 residency of the two weight sets than the phase mixing returns.
+static bool encoder_pipeline_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MILAN_ENC_PIPELINE");
+    v = e ? (atoi(e) != 0) : 0;
+  }
+  return v != 0;
 }
 
 static void alexnet_workspace_dry(const milan_ctx* c, int n, int H, int W,
@@ -866,18 +886,22 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   }
   stage.reset();
 
-  auto pool = [&](const float* tap, int level, int C, int col_off) -> int {
+  // tap: level-`level` tensor of images img0 .. img0 + cnt - 1
+  auto pool = [&](const float* tap, int level, int C, int col_off, int img0 = 0,
+                  int cnt = -1) -> int {
     if (spatial) return 0;
+    if (cnt < 0) cnt = n;
+    if (cnt == 0) return 0;
     StageScope scope(MILAN_STAGE_ENC_POOL, s);
     const int P = pl.lv.h[level] * pl.lv.w[level];
     if (split && level > 0)
-      hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
+      hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off);
+                         pl.list_w, pl.list_n, features, F, col_off, img0);
     else
-      hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(n, (C + 63) / 64),
+      hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off);
+                         pl.list_w, pl.list_n, features, F, col_off, img0);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   };
@@ -921,7 +945,23 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   // 4. bottleneck stages; tap after each stage
   float *x = pl.x0, *y = pl.x1;
   int h = pl.hp, w = pl.wp, col = wd;
-  for (int li = 0; li < 4; ++li) {
+  // Stages whose convolutions all run on the 256x256 split16 kernel (layer3 and
+  // layer4 of the 64-wide ResNets) are executed as a two-half software
+  // pipeline (encoder_pipelined_stages below); the loop here stops before them.
+  int first_pipelined = 4;
+  if (split && !spatial && n >= 2 && c->d.trunk_kind == MILAN_TRUNK_BOTTLENECK &&
+      encoder_pipeline_enabled()) {
+    first_pipelined = 4;
+    for (int li = 3; li >= 1; --li) {
+      bool ok = true;
+      for (const Bottleneck& b : c->blocks[li])
+        ok = ok && b.c1.cout % 256 == 0 && b.c1.cin % 32 == 0 &&
+             (!b.has_down || b.c3d.ws != nullptr);
+      if (!ok) break;
+      first_pipelined = li;
+    }
+  }
+  for (int li = 0; li < first_pipelined; ++li) {
     stage.emplace(MILAN_STAGE_ENC_LAYER1 + li, s);
     for (const Bottleneck& b : c->blocks[li]) {
       int h1, w1, h2, w2, h3, w3;
@@ -989,6 +1029,101 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                   "internal: stage %d geometry mismatch", li + 1);
     MILAN_TRY(pool(x, li + 1, C, col));
     col += C;
+  }
+  if (first_pipelined < 4) {
+    // ---- two-half software pipeline over the late stages ---------------------
+    // The batch is split into halves A and B that run the same chain of
+    // convolutions one op apart: launch j holds op j of A and op j-1 of B in ONE
+    // grid (launch_gemm_pair).  Consecutive ops of a bottleneck alternate
+    // between matrix-core-bound (1x1 reduce, 3x3) and HBM-bound (1x1 expand:
+    // residual read + 4x wider store), so every launch mixes the two kinds and
+    // the expand convs' epilogues overlap the other half's MFMA loops.  Results
+    // are bitwise those of the plain schedule (same kernel, same tiles per
+    // output row).  Half B's tensors live nA * (buffer extent per image) into
+    // each buffer, so the halves never touch each other's rows.
+    struct Op {
+      bool is_pool = false;
+      GemmArgs g{};
+      const float* tap = nullptr; int level = 0, C = 0, col = 0, img0 = 0, cnt = 0;
+      int stage = 0;
+    };
+    const int nA = n / 2, nB = n - nA;
+    auto gen = [&](int img0, int cnt, std::vector<Op>& ops) -> int {
+      // this half's input: the dense tensor the previous stages left in x
+      const float* in = x + (size_t)img0 * h * w *
+                                ((size_t)c->blocks[first_pipelined][0].c1.cin);
+      float* bx = x;  // buffer holding the current tensor
+      float* by = y;
+      int hh = h, ww = w, ccol = col;
+      for (int li = first_pipelined; li < 4; ++li) {
+        for (const Bottleneck& b : c->blocks[li]) {
+          int h1, w1, h2, w2, h3, w3;
+          float* t1 = pl.t1 + (size_t)img0 * pl.t1_sz;
+          float* t2 = pl.t2 + (size_t)img0 * pl.t2_sz;
+          float* out = by + (size_t)img0 * pl.x_sz;
+          Op o1, o2, o3;
+          o1.stage = o2.stage = o3.stage = MILAN_STAGE_ENC_LAYER1 + li;
+          o1.g = conv_args(b.c1, in, cnt, hh, ww, t1, EPI_BIAS_RELU, nullptr,
+                           c->zero, &h1, &w1, true);
+          o2.g = conv_args(b.c2, t1, cnt, h1, w1, t2, EPI_BIAS_RELU, nullptr,
+                           c->zero, &h2, &w2, true);
+          if (b.has_down) {
+            // c3 and the downsample as ONE GEMM over [t2 | x(strided)]
+            o3.g = conv_args(b.c3d, t2, cnt, h2, w2, out, EPI_BIAS_RELU, nullptr,
+                             c->zero, &h3, &w3, true);
+            o3.g.Cin = b.c3.cin;
+            o3.g.a_pix_stride = b.c3.cin;
+            o3.g.a_img_stride = (long)h2 * w2 * b.c3.cin;
+            o3.g.A2 = in; o3.g.K1 = b.c3.K; o3.g.H2 = hh; o3.g.W2d = ww;
+            o3.g.stride2 = b.down.stride;
+            o3.g.a2_pix_stride = b.down.cin;
+            o3.g.a2_img_stride = (long)hh * ww * b.down.cin;
+            o3.g.flop_k = b.c3.K + b.down.K;
+          } else {
+            o3.g = conv_args(b.c3, t2, cnt, h2, w2, out, EPI_BIAS_RES_RELU, in,
+                             c->zero, &h3, &w3, true);
+          }
+          ops.push_back(o1); ops.push_back(o2); ops.push_back(o3);
+          in = out;
+          float* tmp = bx; bx = by; by = tmp;
+          hh = h3; ww = w3;
+        }
+        const int C = (wd * 4) << li;
+        MILAN_REQUIRE(hh == pl.lv.h[li + 1] && ww == pl.lv.w[li + 1],
+                      MILAN_ERR_SHAPE, "internal: stage %d geometry mismatch",
+                      li + 1);
+        Op pp;
+        pp.is_pool = true; pp.tap = in; pp.level = li + 1; pp.C = C;
+        pp.col = ccol; pp.img0 = img0; pp.cnt = cnt;
+        pp.stage = MILAN_STAGE_ENC_LAYER1 + li;
+        ops.push_back(pp);
+        ccol += C;
+      }
+      return 0;
+    };
+    std::vector<Op> opsA, opsB;
+    MILAN_TRY(gen(0, nA, opsA));
+    MILAN_TRY(gen(nA, nB, opsB));
+    const size_t L = opsA.size();
+    for (size_t j = 0; j <= L; ++j) {
+      const Op* a = j < L ? &opsA[j] : nullptr;
+      const Op* b = j >= 1 ? &opsB[j - 1] : nullptr;
+      if (a && b && !a->is_pool && !b->is_pool) {
+        StageScope scope(a->stage, s);  // (B's op is one step behind)
+        MILAN_TRY(launch_gemm_pair(a->g, b->g, s));
+        continue;
+      }
+      for (const Op* o : {a, b}) {
+        if (!o) continue;
+        if (o->is_pool) {
+          MILAN_TRY(pool(o->tap, o->level, o->C, o->col, o->img0, o->cnt));
+        } else {
+          StageScope scope(o->stage, s);
+          MILAN_TRY(launch_gemm(o->g, s));
+        }
+      }
+    }
+    return 0;
   }
   if (spatial) {
     // layer4 output, NHWC == the reference's permute(0, 2, 3, 1): (n, h*w, C)
@@ -1178,11 +1313,11 @@ static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (tap_split)
       hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
                          dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col);
+                         pl.list_w, pl.list_n, features, F, col, 0);
     else
       hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(n, (C + 63) / 64),
                          dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col);
+                         pl.list_w, pl.list_n, features, F, col, 0);
     MILAN_CHECK_HIP(hipGetLastError());
     col += C;
     return 0;

@@ -549,9 +549,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_kernel(
 // stores k-chunk p ^ ((r>>2)&3) (conflict-free for the DMA write and for the
 // row-per-lane ds_read_b128).
 // ---------------------------------------------------------------------------
+// XCD-aware bijective remap (block b runs on XCD b % 8): each XCD walks a
+// contiguous range of the T tiles.
+__device__ __forceinline__ int xcd_tile(int b, int T) {
+  const int q = T >> 3, r = T & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int BM, int BN, int STAGES, int SHAPE>
-__global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_kernel(
-    GemmArgs g, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
+                                             int tile_n) {
   constexpr int BK = 16;
   constexpr int TM = 4, TN = 2;               // wave tile 128 x 64
   constexpr int WAVES_N = BN / 64;
@@ -568,16 +576,6 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  int tile;
-  {
-    const int T = tiles_m * tiles_n;
-    const int b = blockIdx.x;
-    const int q = T >> 3, r = T & 7;
-    const int xcd = b & 7, idx = b >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 
   // loader: NT threads cover NT/4 rows x 4 chunks per pass
   const int lrow = tid >> 2;                        // 0..LROWS-1
@@ -790,6 +788,51 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   }
   run_epilogue<TM, TN>(g, acc, smem, wave, lane, tile_m * BM + wm * 128,
                        tile_n * BN + wn * 64);
+}
+
+template <int BM, int BN, int STAGES, int SHAPE>
+__global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_kernel(
+    GemmArgs g, int tiles_m, int tiles_n) {
+  const int tile = xcd_tile(blockIdx.x, tiles_m * tiles_n);
+  const int tile_m = tile / tiles_n;
+  split16_tile<BM, BN, STAGES, SHAPE>(g, tile_m, tile - tile_m * tiles_n);
+}
+
+// Two independent problems in ONE launch, their tiles interleaved in proportion
+// on every XCD.  Used by the encoder to run a bandwidth-bound convolution of one
+// half of the batch (the 1x1 expand convs: residual read + full-width store)
+// next to a matrix-core-bound one of the other half (the 3x3 / 1x1 reduce
+// convs), so that the HBM-bound epilogues of the first overlap the MFMA main
+// loops of the second on the chip instead of every CU hitting the same phase.
+struct GemmPair {
+  GemmArgs g[2];
+  int tiles_m[2], tiles_n[2];
+};
+
+__device__ __forceinline__ void xcd_range(int T, int xcd, int* start, int* count) {
+  const int q = T >> 3, r = T & 7;
+  *count = q + (xcd < r ? 1 : 0);
+  *start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+}
+
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_pair_kernel(
+    GemmPair p) {
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  int s0, c0, s1, c1;
+  xcd_range(p.tiles_m[0] * p.tiles_n[0], xcd, &s0, &c0);
+  xcd_range(p.tiles_m[1] * p.tiles_n[1], xcd, &s1, &c1);
+  if (j >= c0 + c1) return;  // grid is padded to 8 * max per-XCD count
+  // Bresenham interleave: a(j) = floor(j c0 / (c0 + c1)) problem-0 tiles precede
+  // local slot j
+  const int a0 = (int)((long)j * c0 / (c0 + c1));
+  const int a1 = (int)((long)(j + 1) * c0 / (c0 + c1));
+  const int which = a1 > a0 ? 0 : 1;
+  const int tile = which == 0 ? s0 + a0 : s1 + (j - a0);
+  const GemmArgs& g = p.g[which];
+  const int tn = p.tiles_n[which];
+  const int tile_m = tile / tn;
+  split16_tile<BM, BN, STAGES, 0>(g, tile_m, tile - tile_m * tn);
 }
 
 // ---------------------------------------------------------------------------
@@ -1053,11 +1096,10 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
                     "Cin %% 8 == 0 and N <= 64 (Cin=%d N=%d)", g.Cin, g.N);
       return launch_cfg<256, 64, 2, false, true>(g, s);
     }
-    if (g.N <= 64) {
-      if (g.tile_hint == 6) return launch_split16<512, 64, 3>(g, s);
-      if (g.tile_hint == 7) return launch_split16<256, 64, 4>(g, s);
-      return launch_cfg<256, 64, 2, true, true>(g, s);
-    }
+    // (N <= 64 on the split16 pipeline -- 512x64x3 / 256x64x4 tiles -- measured
+    // 10-20 % SLOWER in round 2: these layers are bound by the L2 -> LDS operand
+    // traffic of a 64-column tile, not by the pipeline depth.)
+    if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
     // Measured on the 4096-neuron workload (profiles/): the 4-wave 256x128
     // tile with 16-slot k-tiles, a 3-deep ring and DMA pieces interleaved with
     // the MFMA groups (2 workgroups per CU) is the fastest split-mode
@@ -1085,6 +1127,73 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     return launch_cfg<256, 128, 3, true, false>(g, s);
   return cin32 ? launch_cfg<128, 128, 2, true, false>(g, s)
                : launch_cfg<128, 128, 2, false, false>(g, s);
+}
+
+// true when launch_gemm would run g on the 256x256x4 split16 kernel
+static bool uses_split16_256(const GemmArgs& g) {
+  return g.a_split && g.Cin % 32 == 0 && g.N > 64 && g.N % 256 == 0 &&
+         g.tile_hint == 0 && env_tile_hint() == 0 &&
+         env_tile_override(g.N, g.K) == 0;
+}
+
+static int finish_args(GemmArgs& g) {  // what launch_gemm_impl derives
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("MILAN_ABLATE"); dbg = e ? atoi(e) : 0; }
+  g.debug = dbg;
+  MILAN_REQUIRE(g.out_split && g.N % 8 == 0 && g.ldc % 8 == 0 && aligned16(g.C) &&
+                    (g.bias == nullptr || aligned16(g.bias)) &&
+                    (g.aux == nullptr ||
+                     (g.aux_split && g.ldaux % 8 == 0 && aligned16(g.aux))),
+                MILAN_ERR_SHAPE, "gemm pair: needs split-format outputs");
+  g.out_mode = OUT_SPLIT8;
+  if (g.acc_scale == 0.f) g.acc_scale = 1.f;
+  return 0;
+}
+
+int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("MILAN_GEMM_PAIR"); off = e && atoi(e) == 0; }
+  if (off || !uses_split16_256(a) || !uses_split16_256(b) || !a.out_split ||
+      !b.out_split) {
+    MILAN_TRY(launch_gemm(a, s));
+    return launch_gemm(b, s);
+  }
+  constexpr int BM = 256, BN = 256, STAGES = 4;
+  GemmPair p;
+  p.g[0] = a; p.g[1] = b;
+  int per_xcd = 0;
+  for (int i = 0; i < 2; ++i) {
+    MILAN_TRY(finish_args(p.g[i]));
+    p.tiles_m[i] = (p.g[i].M + BM - 1) / BM;
+    p.tiles_n[i] = (p.g[i].N + BN - 1) / BN;
+  }
+  per_xcd = (p.tiles_m[0] * p.tiles_n[0] + 7) / 8 + (p.tiles_m[1] * p.tiles_n[1] + 7) / 8;
+  constexpr int NT = (BM / 128) * (BN / 64) * 64;
+  const size_t lds = size_t(STAGES) * (BM + BN) * 16 * sizeof(float);
+  auto kern = igemm_split16_pair_kernel<BM, BN, STAGES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kern),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  ProfRec* e = nullptr;
+  if (g_prof.on) {
+    e = prof_next();
+    MILAN_REQUIRE(e != nullptr, MILAN_ERR_STATE, "profiler: cannot create events");
+    e->stage = g_prof.stage;
+    e->gemm = true;
+    e->flops = 0.0;
+    for (int i = 0; i < 2; ++i)
+      e->flops += 2.0 * (double)p.g[i].M * (double)p.g[i].N *
+                  (double)(p.g[i].flop_k > 0 ? p.g[i].flop_k : p.g[i].K);
+    MILAN_CHECK_HIP(hipEventRecord(e->a, s));
+  }
+  hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(NT), lds, s, p);
+  MILAN_CHECK_HIP(hipGetLastError());
+  if (e) MILAN_CHECK_HIP(hipEventRecord(e->b, s));
+  return 0;
 }
 
 int launch_gemm(const GemmArgs& g, hipStream_t s) {

@@ -754,7 +754,8 @@ def make_dims(state_dict: Dict[str, torch.Tensor],
         vocab = sd['output.1.weight'].shape[0]
     else:
         hidden, emb, att, vocab = 4, 4, 4, n_vocab_tokens + 4
-        feat = _FEATURE_MULT[kind] * width
+        # encoder-only context, or a standalone LanguageModel (no trunk either)
+        feat = _FEATURE_MULT[kind] * width if kind is not None else 4
     if width is None:
         # decoder-only context (foreign Encoder, like the reference accepts any
         # `feature_shape`): no trunk, feature size only GEMM-aligned

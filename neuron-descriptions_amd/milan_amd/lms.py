@@ -3,8 +3,10 @@
 Mirror of the reference's `src/milan/lms.py:17-101` (inference surface):
 Embedding(V,E,padding_idx) -> 2-layer LSTM -> Linear(V) + LogSoftmax, and
 `forward(inputs, reduce=True)` = masked sequence log-probability with the
-reference's stop-mask off-by-one (lms.py:93-96).  Training (`fit`) and text
-scoring (`logp`, needs the spaCy tokenizer) are out of scope.
+reference's stop-mask off-by-one (lms.py:93-96).  Works attached to a Decoder
+(sharing its HIP context) or standalone, like the reference's module.
+Training (`fit`) and text scoring (`logp`, needs the spaCy tokenizer) are out
+of scope.
 """
 from typing import Any, Mapping, Optional
 
@@ -41,7 +43,25 @@ class LanguageModel(nn.Module):
         spec['output.0.weight'] = ((v, h), f)
         spec['output.0.bias'] = ((v,), f)
         params.build(spec, root=self)
-        self._owner = None  # set by Decoder: scoring runs in its HIP context
+        # inside a Decoder the LM scores through the decoder's HIP context (one
+        # packed copy of the weights); on its own it builds an LM-only context
+        self._owner = None
+        self._ctx: Optional[hip.Context] = None
+        self._ctx_key = None
+
+    def _context(self) -> hip.Context:
+        if self._owner is not None and self._owner() is not None:
+            return self._owner()._context()
+        device = hip.require_device(self.embedding.weight.device)
+        key = (device, tuple(p._version for p in self.parameters()))
+        if self._ctx is None or self._ctx_key != key:
+            sd = {f'lm.{k}': v for k, v in self.state_dict().items()}
+            dims = hip.make_dims(sd, len(self.indexer.vocab))
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = hip.Context(dims, sd, device)
+            self._ctx_key = key
+        return self._ctx
 
     def forward(self,
                 inputs: torch.Tensor,
@@ -56,11 +76,7 @@ class LanguageModel(nn.Module):
         reference's off-by-one: the term predicting the token AFTER the stop
         still counts (lms.py:93-95).
         """
-        if self._owner is None:
-            raise hip.HipUnavailableError(
-                'LanguageModel scores through its Decoder\'s HIP context; '
-                'attach it to a milan_amd.Decoder first')
-        ctx = self._owner()._context()
+        ctx = self._context()
         if reduce and masks is None:
             return ctx.lm_score(inputs)  # fused: never materialises (B,L,V)
         lps = ctx.lm_logprobs(inputs)
