@@ -389,13 +389,16 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       const float* residual, float* y, int precision,
                       milan_stream stream) {
   MILAN_REQUIRE(x && weight_oihw && y, MILAN_ERR_ARG, "conv2d: null argument");
+  // precision 2 (test hook only): split-f16 with the LDS-strip 3x3 kernel forced
+  const bool force_strip = precision == 2;
+  if (force_strip) precision = MILAN_PRECISION_SPLIT_F16;
   MILAN_REQUIRE(precision == MILAN_PRECISION_F32 || cin % 32 == 0,
                 MILAN_ERR_SHAPE, "conv2d: split-f16 needs cin %% 32 == 0");
   MILAN_REQUIRE(cin % 4 == 0 && n > 0 && cout > 0, MILAN_ERR_SHAPE,
                 "conv2d: cin must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   const int K = kh * kw * cin, Kp = (K + 31) / 32 * 32;
-  float *wp = nullptr, *zero = nullptr, *xs = nullptr, *wsp = nullptr;
+  float *wp = nullptr, *zero = nullptr, *xs = nullptr, *wsp = nullptr, *ws3 = nullptr;
   MILAN_CHECK_HIP(hipMalloc((void**)&wp, sizeof(float) * (size_t)cout * Kp));
   MILAN_CHECK_HIP(hipMalloc((void**)&zero, 256));
   MILAN_CHECK_HIP(hipMemsetAsync(zero, 0, 256, s));
@@ -423,6 +426,14 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
           r = split_weight_into(wp, cout, Kp, wsp, &g.acc_scale,
                                 reinterpret_cast<unsigned int*>(zero) + 32, s);
         g.A = xs; g.W = wsp; g.a_split = 1;
+        if (r == 0 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && K == Kp) {
+          // the trunk's 3x3 convs run on the LDS-strip kernel: test it the same way
+          if (hipMalloc((void**)&ws3, sizeof(float) * (size_t)cout * Kp) == hipSuccess) {
+            r = make_chunk_major(wsp, cout, cin, ws3, s);
+            g.W3 = ws3;
+            if (force_strip) g.tile_hint = 8;
+          }
+        }
       }
     }
     if (r == 0) r = launch_gemm(g, s);
@@ -432,6 +443,7 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
   (void)hipFree(zero);
   if (xs) (void)hipFree(xs);
   if (wsp) (void)hipFree(wsp);
+  if (ws3) (void)hipFree(ws3);
   if (r == 0 && e != hipSuccess) {
     set_error("conv2d: %s", hipGetErrorString(e));
     r = (int)e;

@@ -74,6 +74,8 @@ struct GemmArgs {
   // optional second operand source (split16 kernels only): k >= K1 reads a
   // 1x1 / stride `stride2` convolution input A2 (H2 x W2d pixels, no padding).
   // Used to fold a bottleneck's downsample conv into its c3 (K-concatenation).
+  const float* W3;    // 3x3 convs: split weights packed chunk-major
+                      // [N][Cin/16][9 taps][16 slots] (conv3x3_split16_kernel)
   const float* A2;
   int K1, H2, W2d, stride2;
   long a2_pix_stride, a2_img_stride;
@@ -132,6 +134,7 @@ inline GemmArgs linear_args(const float* A, long lda, const float* W,
 struct ConvW {
   float* w = nullptr;     // [Cout][Kp]
   float* ws = nullptr;    // same, split-f16 format, scaled by 1/ws_inv
+  float* ws3 = nullptr;   // 3x3 only: ws re-ordered chunk-major (gemm.hip)
   float ws_inv = 1.f;     // exact power of two
   float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
   int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;
@@ -224,6 +227,9 @@ int make_split_weight(milan_ctx* c, const float* w, int n, int kp, float** ws,
 int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
                     float* wp, hipStream_t s);
 int encoder_finalize(milan_ctx* c, hipStream_t s);
+// split 3x3 weights [n][tap][Cin] -> chunk-major [n][Cin/16][tap][16]
+int make_chunk_major(const float* ws, int cout, int cin, float* dst,
+                     hipStream_t s);
 size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W);
 int encoder_run_spatial(milan_ctx* c, const void* images, int image_dtype,
                         const void* masks, int mask_dtype, int n, int H, int W,

@@ -66,6 +66,36 @@ static const Tensor* find(milan_ctx* c, const std::string& name) {
   return it == c->raw.end() ? nullptr : &it->second;
 }
 
+// dst[n][(chunk*9 + tap)*2 + g] = src[n][tap*(Cin/8) + 2*chunk + g] in units of
+// one 8-channel split group (8 floats = [hi x8 | lo x8])
+__global__ void chunk_major_kernel(const float* __restrict__ src, int cout, int cin,
+                                   float* __restrict__ dst) {
+  const int gpr = 9 * (cin / 8);  // groups per row
+  const long total = (long)cout * gpr;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long n = idx / gpr;
+    const int d = idx - n * gpr;
+    const int gsel = d & 1, ct = d >> 1;
+    const int chunk = ct / 9, tap = ct - chunk * 9;
+    const float4* sp = reinterpret_cast<const float4*>(
+        src + (n * gpr + tap * (cin / 8) + 2 * chunk + gsel) * 8);
+    float4* dp = reinterpret_cast<float4*>(dst + idx * 8);
+    dp[0] = sp[0];
+    dp[1] = sp[1];
+  }
+}
+
+int make_chunk_major(const float* ws, int cout, int cin, float* dst,
+                     hipStream_t s) {
+  const long groups = (long)cout * 9 * (cin / 8);
+  const int blocks = (int)((groups + 255) / 256 < 4096 ? (groups + 255) / 256 : 4096);
+  hipLaunchKernelGGL(chunk_major_kernel, dim3(blocks), dim3(256), 0, s, ws, cout,
+                     cin, dst);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static int pack_conv(milan_ctx* c, const std::string& conv,
                      const std::string& bn, int stride, int pad, ConvW* out,
                      hipStream_t s, bool split_without_bn = false) {
@@ -113,9 +143,18 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
                                      hipMemcpyDeviceToDevice, s));
     }
   }
-  if ((g || split_without_bn) && out->cin % 32 == 0)  // split-f16 copy
+  if ((g || split_without_bn) && out->cin % 32 == 0) {  // split-f16 copy
     MILAN_TRY(make_split_weight(c, out->w, out->cout, out->Kp, &out->ws,
                                 &out->ws_inv, s));
+    if (out->ws && out->kh == 3 && out->kw == 3 && out->stride == 1 &&
+        out->pad == 1 && out->Kp == out->K) {
+      // chunk-major copy for the LDS-strip 3x3 kernel: 32-byte groups of 8
+      // channels move from [tap][Cin/8] to [Cin/16][tap][2]
+      MILAN_TRY(dev_alloc(c, (void**)&out->ws3,
+                          sizeof(float) * (size_t)out->cout * out->Kp));
+      MILAN_TRY(make_chunk_major(out->ws, out->cout, out->cin, out->ws3, s));
+    }
+  }
   return 0;
 }
 
@@ -753,6 +792,7 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
   if (split) {
     g.W = cw.ws; g.a_split = 1; g.out_split = 1; g.aux_split = aux != nullptr;
     g.acc_scale = cw.ws_inv;
+    g.W3 = cw.ws3;
   }
   return g;
 }

@@ -835,6 +835,260 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   split16_tile<BM, BN, STAGES, 0>(g, tile_m, tile - tile_m * tn);
 }
 
+
+// ---------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with the input strip resident in LDS.
+//
+// The generic kernels stream the implicit-im2col operand tap by tap: every
+// input pixel crosses L2 -> LDS nine times, and because a tap comes back only
+// Cin/16 k-tiles later the re-reads miss L2 as well (rocprofv3 FETCH_SIZE of
+// layer3's 3x3 convs: 6.4 GB per launch for a 0.77 GB input).  Here K runs
+// channel-chunk-major: for each chunk of 16 channels (one 64-byte split-format
+// row per pixel) the strip of input pixels the 256 output rows of the tile can
+// touch -- rows m0-(W+1) .. m0+255+(W+1) of the flat (image, y, x) pixel list,
+// images are stacked so the strip is one contiguous range -- is DMA'd into LDS
+// ONCE, and the nine taps read their A fragments from it at a per-tap row
+// offset; taps that fall outside the image read a zero row instead (address
+// select per lane).  A-side DMA instructions per 9 k-steps: 3 per wave instead
+// of 72.  The weights stream through the same 4-deep ring as before, packed
+// chunk-major ([n][chunk][tap][16]).  Accumulation order over K differs from
+// the generic kernel (chunk-major), so the layer -> kernel choice stays a pure
+// function of the layer (never of the batch).
+// ---------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(2 * (BN / 64) * 64, 2) void conv3x3_split16_kernel(
+    GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BK = 16, TM = 4, TN = 2, STAGES = 4, AHEAD = 3;
+  constexpr int WAVES_N = BN / 64;
+  constexpr int NT = 2 * WAVES_N * 64;
+  constexpr int LROWS = NT / 4;                 // rows per DMA pass (4 lanes per row)
+  constexpr int B_ITERS = BN / LROWS;           // = 2
+  constexpr int SROWS = 384;                    // strip rows incl. padding
+  constexpr int A_PIECES = SROWS / LROWS;       // 3 (8 waves) or 6 (4 waves)
+  static_assert(B_ITERS == 2 && A_PIECES <= 9, "tile configuration");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                               // [STAGES][BN*16]
+  float* As = smem + STAGES * BN * BK;            // [2][SROWS*16]
+  float* Zs = As + 2 * SROWS * BK;                // 16 floats of zeros
+  float* Ds = Zs + 16;                            // sink of the dummy DMA pieces
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int tile = xcd_tile(blockIdx.x, tiles_m * tiles_n);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  if (tid < 16) Zs[tid] = 0.f;
+
+  const int Wd = g.Wd, H = g.H, Cin = g.Cin;
+  const long m0 = (long)tile_m * BM;
+  const long total_px = (long)g.M;               // output pixels == input pixels
+  const int halo = Wd + 1;
+  const int nchunks = Cin / BK;
+  const int nk = nchunks * 9;
+
+  // ---- DMA lane roles --------------------------------------------------------
+  const int lrow = tid >> 2;                        // row within a pass
+  const int lchunk = tid & 3;
+  // chunk position lchunk of (strip or tile) row r holds k-chunk
+  // lchunk ^ ((r >> 2) & 3); LROWS is a multiple of 16, so the swizzle of a
+  // lane is the same in every pass
+  const int kc = lchunk ^ ((lrow >> 2) & 3);
+  const float* a_lane = g.A + (m0 - halo + lrow) * g.a_pix_stride + kc * 4;
+  const float* rb[B_ITERS];
+#pragma unroll
+  for (int it = 0; it < B_ITERS; ++it) {
+    int n = tile_n * BN + it * LROWS + lrow;
+    n = n < g.N ? n : g.N - 1;
+    rb[it] = g.W3 + (long)n * g.Kp + kc * 4;
+  }
+  // strip piece `piece` = strip rows piece*LROWS + lrow of channel chunk `chunk`
+  // Every k-step issues exactly ONE strip-side piece (so the vmcnt bookkeeping
+  // is a constant and the k-loop has no data-dependent branches): pieces
+  // 0..A_PIECES-1 fill the next chunk's strip, the rest are dummies that read
+  // the zero page into a sink.
+  auto issue_a = [&](int buf, int piece, int chunk) {
+    const int j = piece * LROWS + lrow;
+    const long P = m0 - halo + j;
+    const bool real = piece < A_PIECES;
+    const bool ok = real && P >= 0 && P < total_px && j < BM + 2 * halo;
+    const float* src =
+        ok ? a_lane + (long)piece * LROWS * g.a_pix_stride + chunk * BK : g.zero;
+    float* dst = real ? As + buf * (SROWS * BK) + piece * (LROWS * BK) + wave * (16 * BK)
+                      : Ds + wave * (16 * BK);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)dst,
+                                     16, 0, 0);
+  };
+  auto issue_b = [&](int slot, int kt) {
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      float* dst = Bs + slot * (BN * BK) + it * (LROWS * BK) + wave * (16 * BK);
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(rb[it] + kt * BK),
+                                       (LDS_AS void*)dst, 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addressing ---------------------------------------------------
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int chi = 2 * fhalf;
+  int srow[TM];        // strip row of this lane's output pixel, centre tap
+  unsigned vmask[TM];  // 9 validity bits (tap = 3*dy + dx)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * 128 + i * 32 + frow;
+    long m = m0 + r;
+    m = m < total_px ? m : total_px - 1;
+    const int pix = (int)(m % ((long)H * Wd));
+    const int y = pix / Wd, x = pix - y * Wd;
+    unsigned mk = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const bool ok = (unsigned)(y + dy - 1) < (unsigned)H &&
+                        (unsigned)(x + dx - 1) < (unsigned)Wd;
+        mk |= (ok ? 1u : 0u) << (3 * dy + dx);
+      }
+    vmask[i] = mk;
+    srow[i] = r + halo;
+  }
+  int boff[TN], bswz[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * 64 + j * 32 + frow;
+    boff[j] = row * BK;
+    bswz[j] = (row >> 2) & 3;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue --------------------------------------------------------------
+  // same issue pattern as the steady state ([strip-side piece, weight piece,
+  // weight piece] per k-step) so that ONE vmcnt constant is right from the
+  // first iteration on
+#pragma unroll
+  for (int p = 0; p < A_PIECES; ++p) issue_a(0, p, 0);
+#pragma unroll
+  for (int t = 0; t < AHEAD; ++t) {
+    if (t > 0) issue_a(0, A_PIECES, 0);  // dummy
+    issue_b(t, t < nk ? t : nk - 1);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * (B_ITERS + 1)) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int slot = 0, kt = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* Ab = As + (c & 1) * (SROWS * BK);
+    const int cn = c + 1 < nchunks ? c + 1 : nchunks - 1;  // dummy refill at the end
+    // The tap loop is deliberately NOT unrolled: unrolled, the compiler hoists
+    // the 72 per-(tap, row-tile) fragment addresses out of the chunk loop and
+    // spills; with a runtime tap they are a handful of VALU ops per fragment.
+    int toff = -halo;  // (dy - 1) * W + (dx - 1), advanced incrementally
+    int dx = 0;
+    f32x4 ah[TM], al[TM];
+    const int zoff = (int)(Zs - Ab);
+    auto load_a = [&](int i, int tap, int tap_off) {
+      const int sr = srow[i] + tap_off;
+      const int live = sr * BK + ((chi ^ ((sr >> 2) & 3)) << 2);
+      const int off = ((vmask[i] >> tap) & 1u) ? live : zoff;
+      ah[i] = *reinterpret_cast<const f32x4*>(Ab + off);
+      // lo half: chunk chi + 1 = the neighbouring 16 bytes (positions differ in
+      // bit 0 only); the zero row is 64 B wide so the same flip stays inside it
+      al[i] = *reinterpret_cast<const f32x4*>(Ab + (off ^ 4));
+    };
+    load_a(0, 0, toff);  // the strip of this chunk has landed (barrier above)
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      // DMA pieces of this k-step (one strip piece of the next chunk during the
+      // first A_PIECES taps, two weight pieces for the tile AHEAD k-steps from
+      // now) are issued BETWEEN the MFMA groups, and the A fragments of row-tile
+      // i+1 are fetched under row-tile i's MFMAs.
+      int nslot = slot + AHEAD;
+      nslot = nslot >= STAGES ? nslot - STAGES : nslot;
+      const int ktn = kt + AHEAD < nk ? kt + AHEAD : nk - 1;
+      const float* Bb = Bs + slot * (BN * BK);
+      f32x4 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] + ((chi ^ bswz[j]) << 2));
+        bl[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] + (((chi + 1) ^ bswz[j]) << 2));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        // matrix pipe first: the three MFMAs of (i, 0) are in flight before the
+        // next fragment's address arithmetic / the DMA issue of this group
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+            as_f16x8(ah[i]), as_f16x8(bl[0]), acc[i][0], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+            as_f16x8(al[i]), as_f16x8(bh[0]), acc[i][0], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+            as_f16x8(ah[i]), as_f16x8(bh[0]), acc[i][0], 0, 0, 0);
+        if (i + 1 < TM) load_a(i + 1, t, toff);
+        if (i == 0) issue_a((c + 1) & 1, t, cn);
+        if (i == 1 || i == 2) {
+          const int it = i - 1;
+          float* dst = Bs + nslot * (BN * BK) + it * (LROWS * BK) + wave * (16 * BK);
+          __builtin_amdgcn_global_load_lds(
+              (const GLOBAL_AS void*)(rb[it] + ktn * BK), (LDS_AS void*)dst, 16, 0, 0);
+        }
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+            as_f16x8(ah[i]), as_f16x8(bl[1]), acc[i][1], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+            as_f16x8(al[i]), as_f16x8(bh[1]), acc[i][1], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+            as_f16x8(ah[i]), as_f16x8(bh[1]), acc[i][1], 0, 0, 0);
+      }
+      // next tap's offset; its first A fragments can be fetched BEFORE the
+      // barrier (the strip is complete for the whole chunk -- only the weight
+      // tile needs the barrier), which takes them off the post-barrier bubble
+      if (++dx == 3) { dx = 0; toff += Wd - 2; } else { ++toff; }
+      if (t < 8) load_a(0, t + 1, toff);
+      // tile kt+1 (and, at the last tap, the next strip) must have landed; what
+      // may stay in flight is what was issued after tile kt+1's pieces: the
+      // three pieces of each of the last AHEAD-1 k-steps
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * (B_ITERS + 1)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+      ++kt;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * g.acc_scale;
+  run_epilogue<TM, TN>(g, acc, smem, wave, lane, tile_m * BM + wm * 128,
+                       tile_n * BN + wn * 64);
+}
+
+template <int BN>
+static int launch_conv3x3(const GemmArgs& g, hipStream_t s) {
+  constexpr int NT = 2 * (BN / 64) * 64;
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + BN - 1) / BN;
+  size_t lds = sizeof(float) * (size_t)(4 * BN * 16 + 2 * 384 * 16 + 16 + (NT / 64) * 256);
+  const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
+  if (lds < stage_bytes) lds = stage_bytes;
+  auto kern = conv3x3_split16_kernel<BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kern),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, g, tiles_m,
+                     tiles_n);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // fp32 <-> split-format conversion of a row-major matrix (rows x K, K % 8 == 0)
 // ---------------------------------------------------------------------------
@@ -1054,6 +1308,21 @@ static int env_tile_override(int N, int K) {
   return 0;
 }
 
+// The LDS-strip 3x3 kernel is OFF by default (MILAN_CONV3X3=1 or tile_hint 8
+// turn it on).  MEASURED in round 2 (profiles/r2_conv3x3_strip_experiment.txt):
+// it cuts the HBM fetch of layer3's 3x3 convs from 6.4 GB to under 1 GB per
+// launch and the A-side DMA instructions by 4x, results pass the same parity
+// tests -- and the layers run 8-13 % SLOWER (l3.x.c2 51.8 vs 46.7 ms per
+// pass): the generic kernel's loop-invariant fragment addresses keep its
+// MFMA / ds_read stream tighter than the per-tap address arithmetic here, and
+// the L2/MALL absorbs the re-reads well enough that the saved traffic was not
+// on the critical path.
+static bool conv3x3_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MILAN_CONV3X3"); v = e ? atoi(e) != 0 : 0; }
+  return v != 0;
+}
+
 static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   const bool cin32 = (g.Cin % 32 == 0);
   if (g.tile_hint == 0) g.tile_hint = env_tile_hint();
@@ -1100,6 +1369,14 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     // 10-20 % SLOWER in round 2: these layers are bound by the L2 -> LDS operand
     // traffic of a 64-column tile, not by the pipeline depth.)
     if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
+    // 3x3 / stride 1 with the chunk-major weight copy: input strip in LDS
+    if (g.W3 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.A2 &&
+        g.Cin % 16 == 0 && g.a_pix_stride == g.Cin && g.Ho == g.H && g.Wo == g.Wd &&
+        g.a_img_stride == (long)g.H * g.Wd * g.Cin && g.Wd + 1 <= 64 &&
+        (g.tile_hint == 8 || (g.tile_hint == 0 && conv3x3_enabled()))) {
+      if (g.N % 256 == 0) return launch_conv3x3<256>(g, s);
+      if (g.N % 128 == 0) return launch_conv3x3<128>(g, s);
+    }
     // Measured on the 4096-neuron workload (profiles/): the 4-wave 256x128
     // tile with 16-slot k-tiles, a 3-deep ring and DMA pieces interleaved with
     // the MFMA groups (2 workgroups per CU) is the fastest split-mode
@@ -1131,7 +1408,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
 
 // true when launch_gemm would run g on the 256x256x4 split16 kernel
 static bool uses_split16_256(const GemmArgs& g) {
-  return g.a_split && g.Cin % 32 == 0 && g.N > 64 && g.N % 256 == 0 &&
+  return g.a_split && g.Cin % 32 == 0 && g.N > 64 && g.N % 256 == 0 && !g.W3 &&
          g.tile_hint == 0 && env_tile_hint() == 0 &&
          env_tile_override(g.N, g.K) == 0;
 }

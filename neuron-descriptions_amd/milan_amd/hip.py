@@ -20,6 +20,8 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so'
 GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _RERANK
 PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
 PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16}
+# conv2d_nhwc test hook only: split_f16 with the LDS-strip 3x3 kernel forced
+_CONV_PRECISIONS = dict(PRECISIONS, split_f16_strip=2)
 DTYPE_U8, DTYPE_F32 = 0, 1
 
 ERR_ARG, ERR_SHAPE, ERR_STATE, ERR_WORKSPACE, ERR_NO_LM = -1, -2, -3, -4, -5
@@ -727,7 +729,7 @@ def conv2d_nhwc(x: torch.Tensor,
             lib.milan_conv2d_nhwc(x.data_ptr(), n, h, w, cin,
                                   weight.data_ptr(), _ptr(bias), cout, kh, kw,
                                   stride, padding, int(relu), _ptr(residual),
-                                  y.data_ptr(), PRECISIONS[precision],
+                                  y.data_ptr(), _CONV_PRECISIONS[precision],
                                   _stream(device)))
     return y
 

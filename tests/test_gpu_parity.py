@@ -43,6 +43,12 @@ CONV_CASES = [
     (1, 9, 11, 8, 20, 3, 1, 1),  # ragged everything, Cin%32 != 0
     (5, 7, 7, 512, 2048, 1, 1, 0),  # layer4 shape
     (1, 1, 1, 3904, 512, 1, 1, 0),  # a Linear as a 1x1 conv, M = 1
+    # 3x3 / stride 1, N % 128 == 0: also run on the LDS-strip kernel below
+    (3, 14, 14, 256, 256, 3, 1, 1),  # layer3 c2 shape: tiles span image borders
+    (2, 28, 28, 128, 128, 3, 1, 1),  # layer2 c2 shape (256x128 tile)
+    (5, 7, 7, 64, 512, 3, 1, 1),     # layer4-like: 4 images per tile
+    (1, 9, 37, 32, 128, 3, 1, 1),    # oblong, ragged last tile
+    (2, 61, 63, 32, 128, 3, 1, 1),   # the widest image the strip holds (W + 1 <= 64)
 ]
 
 
@@ -438,6 +444,34 @@ def test_split_f16_conv_error_is_fp32_class(dev, case):
     scale = float(want.abs().max())
     assert errs['split_f16'] <= max(4 * errs['f32'], 2e-6 * scale), errs
     assert errs['split_f16'] <= 1e-5 * scale, errs
+
+
+STRIP_CASES = [c for c in CONV_CASES
+               if c[5] == 3 and c[6] == 1 and c[3] % 32 == 0 and c[4] % 128 == 0]
+
+
+@pytest.mark.parametrize('case', STRIP_CASES)
+def test_lds_strip_conv3x3_kernel(dev, case):
+    """The 3x3 kernel with the input strip resident in LDS (off by default:
+    measured slower) stays correct: fp32-class error
+    against an fp64 reference, tiles spanning image borders, ragged tiles."""
+    assert len(STRIP_CASES) >= 5
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(11 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k))**.5
+    b = torch.randn(cout, generator=g)
+    want = F.conv2d(x.double(), wt.double(), b.double(), stride=1, padding=1)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = {}
+    for prec in ('split_f16', 'split_f16_strip'):
+        y = hip.conv2d_nhwc(x_nhwc, wt.to(dev), b.to(dev), 1, 1, precision=prec)
+        got[prec] = y.permute(0, 3, 1, 2).cpu().double()
+    scale = float(want.abs().max())
+    err = {p: float((v - want).abs().max()) for p, v in got.items()}
+    assert err['split_f16_strip'] <= max(2 * err['split_f16'], 2e-6 * scale), err
+    assert not torch.equal(got['split_f16'], got['split_f16_strip']), \
+        'the strip kernel was not selected (chunk-major K order differs in bits)'
 
 
 def test_split_f16_handles_tiny_and_large_values(dev):

@@ -17,7 +17,7 @@ def main():
     fused = len(sys.argv) > 4 and sys.argv[4] == '1'  # split mode: ds folded into c3
     rows = db.execute(
         "select name, start, end-start, grid_x from kernels where name like "
-        "'%igemm%' order by start").fetchall()
+        "'%igemm%' or name like '%conv3x3%' order by start").fetchall()
     per = len(rows) // passes
     rows = rows[per * (passes - 1):]
     layers = []
@@ -64,7 +64,8 @@ def main():
           sum(r[2] for r in dec) / 1e6)
     others = db.execute(
         "select name, count(*), sum(end-start) from kernels where name not "
-        "like '%igemm%' group by name order by 3 desc limit 12").fetchall()
+        "like '%igemm%' and name not like '%conv3x3%' group by name "
+        "order by 3 desc limit 12").fetchall()
     for nm, c, t in others:
         print(f'  {nm[:60]:60s} x{c:5d} {t/1e6/passes:8.2f} ms/pass')
 
