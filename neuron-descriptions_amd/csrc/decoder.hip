@@ -228,22 +228,50 @@ __global__ __launch_bounds__(256) void attend_kernel(
 }
 
 // ctx[r][f] = sum_k att[r][k] * features[neuron][k][f]   (decoders.py:613)
-// The k attention weights of the row are wave-uniform: they are read straight
-// from global memory (scalar loads), no LDS staging and no barrier.
+// One workgroup per (neuron, 1024-column slice): each thread keeps its float4
+// column of the neuron's k feature rows in registers and walks the neuron's rpn
+// beam rows, so the features cross L2 once per neuron instead of once per row
+// (3 GB -> 60 MB per launch at beam 50).  The k attention weights of a row are
+// wave-uniform and read with scalar loads -- no LDS, no barrier (an earlier
+// LDS-staged variant was not reproducible under multi-process GPU sharing, see
+// DESIGN.md section 6).  Accumulation order per element: k ascending, fmaf.
+constexpr int kCtxMaxK = 16;  // register-resident exemplars (k = 15 in MILAN)
+template <bool RESIDENT>
 __global__ __launch_bounds__(256) void context_kernel(
-    const float* __restrict__ att, const float* __restrict__ feat, int rpn,
-    int k, int F, float* __restrict__ ctx) {
-  const int r = blockIdx.x;
-  const float* ar = att + (long)r * k;
-  const float* fr = feat + (long)(r / rpn) * k * F;
-  for (int f = (blockIdx.y * 256 + threadIdx.x) * 4; f < F;
-       f += gridDim.y * 1024) {
+    const float* __restrict__ att, const float* __restrict__ feat, int rows,
+    int rpn, int k, int F, float* __restrict__ ctx) {
+  const int neuron = blockIdx.x;
+  const int f = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (f >= F) return;
+  const float* fr = feat + (long)neuron * k * F + f;
+  float4 v[RESIDENT ? kCtxMaxK : 1];
+  if constexpr (RESIDENT) {
+#pragma unroll
+    for (int j = 0; j < kCtxMaxK; ++j)
+      v[j] = j < k ? *reinterpret_cast<const float4*>(fr + (long)j * F)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int r0 = neuron * rpn;
+  const int r1 = r0 + rpn < rows ? r0 + rpn : rows;
+  for (int r = r0; r < r1; ++r) {
+    const float* ar = att + (long)r * k;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int j = 0; j < k; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(fr + (long)j * F + f);
-      const float aj = ar[j];
-      s0 = fmaf(aj, v.x, s0); s1 = fmaf(aj, v.y, s1);
-      s2 = fmaf(aj, v.z, s2); s3 = fmaf(aj, v.w, s3);
+    if constexpr (RESIDENT) {
+#pragma unroll
+      for (int j = 0; j < kCtxMaxK; ++j) {
+        if (j < k) {
+          const float aj = ar[j];
+          s0 = fmaf(aj, v[j].x, s0); s1 = fmaf(aj, v[j].y, s1);
+          s2 = fmaf(aj, v[j].z, s2); s3 = fmaf(aj, v[j].w, s3);
+        }
+      }
+    } else {
+      for (int j = 0; j < k; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(fr + (long)j * F);
+        const float aj = ar[j];
+        s0 = fmaf(aj, w.x, s0); s1 = fmaf(aj, w.y, s1);
+        s2 = fmaf(aj, w.z, s2); s3 = fmaf(aj, w.w, s3);
+      }
     }
     *reinterpret_cast<float4*>(ctx + (long)r * F + f) = make_float4(s0, s1, s2, s3);
   }
@@ -1086,9 +1114,14 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
   hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, b->q,
                      keys, c->att_w, c->att_b, rows, rpn, k, A, b->att);
   {
-    int gx = (F / 4 + 255) / 256;
-    hipLaunchKernelGGL(context_kernel, dim3(rows, gx), dim3(256), 0, s, b->att,
-                       features, rpn, k, F, b->ctx);
+    const int gy = (F / 4 + 255) / 256;
+    const int neurons = (rows + rpn - 1) / rpn;
+    if (k <= kCtxMaxK)
+      hipLaunchKernelGGL(context_kernel<true>, dim3(neurons, gy), dim3(256), 0, s,
+                         b->att, features, rows, rpn, k, F, b->ctx);
+    else
+      hipLaunchKernelGGL(context_kernel<false>, dim3(neurons, gy), dim3(256), 0, s,
+                         b->att, features, rows, rpn, k, F, b->ctx);
   }
   // gated = sigmoid(W_g h + b_g) * ctx  -> x[:, E:]
   MILAN_TRY(lin(c, h, H, c->gate, b->x + E, ldx, rows, EPI_BIAS_SIGMUL, s, b->ctx, F));
