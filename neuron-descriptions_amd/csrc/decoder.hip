@@ -290,6 +290,30 @@ __global__ void embed_kernel(const float* __restrict__ table,
   }
 }
 
+// same, written in split format (groups of 8 channels [hi x8 | lo x8])
+__global__ void embed_split_kernel(const float* __restrict__ table,
+                                   const int64_t* __restrict__ tok, int rows, int E,
+                                   float* __restrict__ dst, int ldd) {
+  const int g8 = E >> 3;
+  const long total = (long)rows * g8;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / g8;
+    const int q = idx - r * g8;
+    const float* sp = table + tok[r] * E + q * 8;
+    _Float16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = fminf(fmaxf(sp[e], -65504.f), 65504.f);
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+    float4* d = reinterpret_cast<float4*>(dst + r * ldd + q * 8);
+    d[0] = *reinterpret_cast<const float4*>(hi);
+    d[1] = *reinterpret_cast<const float4*>(lo);
+  }
+}
+
 // torch LSTM cell pointwise, gate order i,f,g,o.
 __global__ void lstm_pointwise_kernel(const float* __restrict__ gates,
                                       const float* __restrict__ c_in, int rows,
@@ -1100,6 +1124,18 @@ int decoder_init_state(milan_ctx* c, const float* features, int n, int k,
   return init_state_impl(c, features, n, k, pooled, h, cc, s);
 }
 
+static void launch_context(const float* att, const float* features, int rows,
+                           int rpn, int k, int F, float* ctx, hipStream_t s) {
+  const int gy = (F / 4 + 255) / 256;
+  const int neurons = (rows + rpn - 1) / rpn;
+  if (k <= kCtxMaxK)
+    hipLaunchKernelGGL(context_kernel<true>, dim3(neurons, gy), dim3(256), 0, s,
+                       att, features, rows, rpn, k, F, ctx);
+  else
+    hipLaunchKernelGGL(context_kernel<false>, dim3(neurons, gy), dim3(256), 0, s,
+                       att, features, rows, rpn, k, F, ctx);
+}
+
 // Everything of Decoder.step up to the vocabulary logits, for `rows` rows that
 // share features in groups of `rpn`.  x = [emb | gated] is built in b->x.
 static int step_core(milan_ctx* c, const float* features, const float* keys,
@@ -1110,19 +1146,61 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
   const int F = d.feature_size, H = d.hidden_size, E = d.embedding_size,
             A = d.attention_size, V = d.vocab_size;
   const int ldx = E + F;
+  // Split-f16 mode with every weight in split form: h is converted ONCE (it
+  // feeds three GEMMs), and the LSTM input x = [emb | gated context] is produced
+  // directly in split format -- the gate GEMM's epilogue writes its half, the
+  // embedding gather the other -- so the (rows, E+F) matrix is never converted
+  // (470 -> 50 MB of conversion traffic per step).  Same bits as converting.
+  const bool fused = c->precision == MILAN_PRECISION_SPLIT_F16 && c->scratch &&
+                     c->q2h.ws && c->gate.ws && c->lstm_cat.ws && c->out.ws &&
+                     E % 16 == 0 && F % 8 == 0 && H % 16 == 0 &&
+                     (size_t)rows * (ldx + H) <= c->scratch_floats;
+  if (fused) {
+    float* xs = c->scratch;                       // (rows, E+F) split
+    float* hs = c->scratch + (size_t)rows * ldx;  // (rows, H) split
+    MILAN_TRY(launch_f32_to_split(h, H, hs, H, rows, H, 1.f, s));
+    auto split_lin = [&](const LinearW& w, float* C, int ldc, int epi,
+                         const float* aux, int ldaux) {
+      GemmArgs g = linear_args(hs, H, w.ws, w.b, C, ldc, rows, w.n, w.k, epi,
+                               c->zero, aux, ldaux);
+      g.a_split = 1;
+      g.acc_scale = w.ws_inv;
+      return g;
+    };
+    MILAN_TRY(launch_gemm(split_lin(c->q2h, b->q, A, EPI_BIAS, nullptr, 0), s));
+    hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, b->q,
+                       keys, c->att_w, c->att_b, rows, rpn, k, A, b->att);
+    launch_context(b->att, features, rows, rpn, k, F, b->ctx, s);
+    {
+      GemmArgs g = split_lin(c->gate, xs + E, ldx, EPI_BIAS_SIGMUL, b->ctx, F);
+      g.out_split = 1;  // aux stays fp32
+      MILAN_TRY(launch_gemm(g, s));
+    }
+    hipLaunchKernelGGL(embed_split_kernel, dim3(nblk((long)rows * (E / 8))),
+                       dim3(256), 0, s, c->embedding, tok, rows, E, xs, ldx);
+    {
+      // gates = [x | h] [W_ih | W_hh]^T: x from xs (k < E+F), h from hs
+      const LinearW& w = c->lstm_cat;
+      GemmArgs g = linear_args(xs, ldx, w.ws, w.b, b->gates, 4 * H, rows, w.n,
+                               w.k, EPI_BIAS, c->zero);
+      g.a_split = 1;
+      g.acc_scale = w.ws_inv;
+      g.Cin = ldx;  // geometry of source 1
+      g.A2 = hs; g.K1 = ldx; g.H2 = 1; g.W2d = 1; g.stride2 = 1;
+      g.a2_pix_stride = H; g.a2_img_stride = H;
+      MILAN_TRY(launch_gemm(g, s));
+    }
+    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * H)),
+                       dim3(256), 0, s, b->gates, cc, rows, H, hn, cn);
+    MILAN_TRY(launch_f32_to_split(hn, H, hs, H, rows, H, 1.f, s));
+    MILAN_TRY(launch_gemm(split_lin(c->out, b->logits, V, EPI_BIAS, nullptr, 0), s));
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   MILAN_TRY(lin(c, h, H, c->q2h, b->q, A, rows, EPI_BIAS, s));
   hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, b->q,
                      keys, c->att_w, c->att_b, rows, rpn, k, A, b->att);
-  {
-    const int gy = (F / 4 + 255) / 256;
-    const int neurons = (rows + rpn - 1) / rpn;
-    if (k <= kCtxMaxK)
-      hipLaunchKernelGGL(context_kernel<true>, dim3(neurons, gy), dim3(256), 0, s,
-                         b->att, features, rows, rpn, k, F, b->ctx);
-    else
-      hipLaunchKernelGGL(context_kernel<false>, dim3(neurons, gy), dim3(256), 0, s,
-                         b->att, features, rows, rpn, k, F, b->ctx);
-  }
+  launch_context(b->att, features, rows, rpn, k, F, b->ctx, s);
   // gated = sigmoid(W_g h + b_g) * ctx  -> x[:, E:]
   MILAN_TRY(lin(c, h, H, c->gate, b->x + E, ldx, rows, EPI_BIAS_SIGMUL, s, b->ctx, F));
   hipLaunchKernelGGL(embed_kernel, dim3(nblk((long)rows * E)), dim3(256), 0, s,

@@ -190,7 +190,10 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
     // current one: C and aux are not provably distinct, so without the explicit
     // early loads every load would wait behind the previous store and the
     // epilogue would pay one HBM round trip per 8 rows.
-    constexpr bool RES = (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD);
+    // RES: split-format residual; SIGMUL: fp32 multiplicand (the decoder's
+    // gated context, written straight into the LSTM's split-format input)
+    constexpr bool SIG = EPI == EPI_BIAS_SIGMUL;
+    constexpr bool RES = (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD || SIG);
     f32x4 res[RES ? 2 : 1][4][2];
     auto load_res = [&](int i, f32x4 (&r)[4][2]) {
 #pragma unroll
@@ -228,7 +231,14 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
             v[e] = v0[e] + bias8[e];
             v[4 + e] = v1[e] + bias8[4 + e];
           }
-          if constexpr (RES) {
+          if constexpr (SIG) {
+            const f32x4 a0 = res[i & 1][it][0], a1 = res[i & 1][it][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = (1.f / (1.f + expf(-v[e]))) * a0[e];
+              v[4 + e] = (1.f / (1.f + expf(-v[4 + e]))) * a1[e];
+            }
+          } else if constexpr (RES) {
             float a[8];
             join8(res[i & 1][it][0], res[i & 1][it][1], a);
 #pragma unroll
@@ -293,6 +303,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
       case EPI_BIAS_RELU: epilogue_split8(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
       case EPI_BIAS_RES_RELU: epilogue_split8(std::integral_constant<int, EPI_BIAS_RES_RELU>{}); break;
       case EPI_BIAS_ADD: epilogue_split8(std::integral_constant<int, EPI_BIAS_ADD>{}); break;
+      case EPI_BIAS_SIGMUL: epilogue_split8(std::integral_constant<int, EPI_BIAS_SIGMUL>{}); break;
       default: epilogue_split8(std::integral_constant<int, EPI_BIAS>{}); break;
     }
   } else if (g.out_mode == OUT_VEC4) {
@@ -1337,10 +1348,12 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     MILAN_REQUIRE(g.out_split && g.N % 8 == 0 && g.ldc % 8 == 0 && aligned16(g.C) &&
                       (g.bias == nullptr || aligned16(g.bias)) &&
                       (g.aux == nullptr ||
-                       (g.aux_split && g.ldaux % 8 == 0 && aligned16(g.aux))) &&
+                       ((g.aux_split || g.epilogue == EPI_BIAS_SIGMUL) &&
+                        g.ldaux % 8 == 0 && aligned16(g.aux))) &&
                       (g.epilogue == EPI_BIAS || g.epilogue == EPI_BIAS_RELU ||
                        g.epilogue == EPI_BIAS_RES_RELU ||
-                       g.epilogue == EPI_BIAS_ADD),
+                       g.epilogue == EPI_BIAS_ADD ||
+                       (g.epilogue == EPI_BIAS_SIGMUL && !g.aux_split)),
                   MILAN_ERR_SHAPE,
                   "gemm: unsupported split-format epilogue (N=%d ldc=%d epi=%d)",
                   g.N, g.ldc, g.epilogue);
