@@ -336,3 +336,21 @@ def test_two_rank_bench_equals_one_rank(world):
     assert (two['config']['gathered_tokens_sha256'] ==
             one['config']['gathered_tokens_sha256'])
     assert two['roofline']['stages'], 'per-stage roofline missing'
+
+
+def test_two_rank_bench_weak_mode_all_legs(world):
+    """The driver's multi-GPU command line (weak scaling: --steps per rank)
+    with every leg on: resident run, PCIe-inclusive leg, f32 leg, gather."""
+    args = ['--steps', '2', '--chunk', '32', '--warmup', '1', '--cpu-sample',
+            '0', '--also-f32-steps', '1', '--beam', '8']
+    out = _bench(args, 2, 29950 + os.getpid() % 40)
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak'
+    assert out['steps'] == 2 and out['warmup'] == 1
+    assert out['config']['neurons_total'] == 2 * 2 * 32
+    assert out['config']['gathered_tokens'] == [128, LENGTH]
+    assert out['value'] > 0 and out['pcie_inclusive']['value'] > 0
+    assert out['pcie_inclusive']['steps'] == 2
+    assert out['f32_mode']['steps'] == 1 and out['f32_mode']['value'] > 0
+    assert out['cpu_baseline'] is None and 'other_configs' not in out
+    names = [st['stage'] for st in out['roofline']['stages']]
+    assert 'encoder.layer3' in names and 'decoder.search' in names

@@ -383,6 +383,20 @@ def test_world_size_two_broadcast_and_gather_over_gloo(tmp_path):
     assert (tmp_path / 'ok1').read_text() == 'True'
 
 
+def test_exemplars_fail_loudly_without_gpu():
+    """No CPU fallback in the exemplar computation either."""
+    from milan_amd import exemplars
+    model = synthetic.exemplar_model(3, 2, 0)
+    dataset = torch.utils.data.TensorDataset(synthetic.exemplar_images(4, 16, 1))
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a GPU')
+    with pytest.raises(hip.HipUnavailableError):
+        exemplars.discriminative(model, dataset, layer='conv_2', k=2,
+                                 image_size=16, num_workers=0)
+    with pytest.raises(hip.HipUnavailableError):
+        exemplars.RunningTopK(k=2).add(torch.zeros(3, 4))
+
+
 def test_graft_entry_build_runs():
     """`__graft_entry__.build()` is the driver's "does it build" check."""
     import __graft_entry__
