@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MILAN_ABI_VERSION 4
+#define MILAN_ABI_VERSION 5
 
 enum {
   MILAN_OK = 0,
@@ -303,6 +303,32 @@ int milan_exemplar_sketch_compact(const float* src, int64_t src_capacity,
                                   int64_t dst_capacity, int64_t position,
                                   float* extremes, void* workspace,
                                   size_t workspace_bytes, milan_stream stream);
+
+/* RunningQuantile._add_every for a whole batch (runningstats.py:363-407): the
+ * sketch's control flow depends on buffer sizes only, so it is played forward on
+ * the host and executed level by level -- one launch per level, every compaction
+ * of a level in parallel -- instead of one append + one compaction launch per
+ * 128..8192 samples.  Consumes activation rows [first, batch*hw) of `hiddens`
+ * (row order as milan_exemplar_sketch_append).  levels / firstfree / capacities:
+ * HOST arrays of n_levels entries (device row pointers; fill counts, updated on
+ * return; row capacities, each in [2, 8192]).  randbits: HOST array of the
+ * caller's random bits (torch's, so that seeded runs match the reference),
+ * *currentbit the index of the last one used, updated on return.  Stops early --
+ * *consumed < batch*hw - first, level 0 full -- before a _shift() that needs
+ * _expand() or more random bits than remain: the caller performs that one
+ * _shift() (milan_exemplar_sketch_compact) and calls again.  Same results as
+ * the per-operation path, bit for bit. */
+size_t milan_exemplar_sketch_add_workspace(int n_units, int64_t supplied,
+                                           const int64_t* capacities,
+                                           int n_levels);
+int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int hw,
+                              const int32_t* units, int n_units, int64_t first,
+                              int64_t* consumed, float* const* levels,
+                              int64_t* firstfree, const int64_t* capacities,
+                              int n_levels, const uint8_t* randbits,
+                              int64_t n_randbits, int64_t* currentbit,
+                              float* extremes, void* workspace,
+                              size_t workspace_bytes, milan_stream stream);
 
 /* RunningQuantile.quantiles(q) for one q (runningstats.py:531-580): weighted
  * summary of all levels (level l has weight 2^l), stable sort, float32

@@ -15,6 +15,7 @@
 // the reference; the kernels below are its tensor operations.
 #include "common.h"
 
+#include <vector>
 #include <hipcub/hipcub.hpp>
 
 namespace milan {
@@ -173,6 +174,99 @@ __global__ __launch_bounds__(1024) void sketch_sort_decimate_kernel(
   if (extremes && tid == 0) {
     extremes[2 * u] = fminf(extremes[2 * u], v[0]);
     extremes[2 * u + 1] = fmaxf(extremes[2 * u + 1], v[n - 1]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Bulk add: the sketch's state machine (which level is compacted when, over how
+// many samples, with which random bit) depends on buffer sizes only, never on
+// the data.  milan_exemplar_sketch_add therefore plays it forward on the host
+// for a whole batch and executes the result level by level: level l sees a
+// STREAM S_l = [what the level buffer held | what level l-1 emitted, in order],
+// its compactions are consecutive ranges of that stream, all independent -- one
+// launch per level, one workgroup per (range, unit) -- and what is left of the
+// stream after the last range is the level's new buffer content.  A conv1-sized
+// batch (400 k samples per unit, ~5000 compactions) is ~15 launches instead of
+// ~10 000.
+// ---------------------------------------------------------------------------
+struct SketchOp { int start, n, offset, outpos; };
+
+struct SketchSource {  // S_0's tail: activation rows of the batch
+  const float* hid; const int32_t* units; int channels, hw; long first;
+};
+
+template <bool SOURCE>
+__device__ __forceinline__ float sketch_stream_at(
+    const float* __restrict__ init, long init_capacity, int init_len,
+    const float* __restrict__ in, long in_stride, const SketchSource& src, int u,
+    long s) {
+  if (s < init_len) return init[(long)u * init_capacity + s];
+  long p = s - init_len;
+  if (SOURCE) {
+    p += src.first;
+    const long img = p / src.hw;
+    const int sp = (int)(p - img * src.hw);
+    const int ch = src.units ? src.units[u] : u;
+    return src.hid[(img * src.channels + ch) * src.hw + sp];
+  }
+  return in[(long)u * in_stride + p];
+}
+
+template <bool SOURCE>
+__global__ __launch_bounds__(1024) void sketch_level_kernel(
+    const float* __restrict__ init, long init_capacity, int init_len,
+    const float* __restrict__ in, long in_stride, SketchSource src,
+    const SketchOp* __restrict__ ops, float* __restrict__ out, long out_stride) {
+  extern __shared__ float sv[];
+  const SketchOp op = ops[blockIdx.x];
+  const int u = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+  int P = 2;
+  while (P < op.n) P <<= 1;
+  for (int i = tid; i < P; i += nt)
+    sv[i] = i < op.n ? sketch_stream_at<SOURCE>(init, init_capacity, init_len, in,
+                                                in_stride, src, u,
+                                                (long)op.start + i)
+                     : INFINITY;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += nt) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi = lo | stride;
+        const float a = sv[lo], b = sv[hi];
+        const bool up = (lo & size) == 0;
+        if (up ? (a > b) : (a < b)) { sv[lo] = b; sv[hi] = a; }
+      }
+      __syncthreads();
+    }
+  const int m = (op.n - op.offset + 1) / 2;
+  for (int j = tid; j < m; j += nt)
+    out[(long)u * out_stride + op.outpos + j] = sv[op.offset + 2 * j];
+}
+
+// extremes over S_0[0, n): everything that went through a level-0 compaction
+__global__ __launch_bounds__(256) void sketch_stream_extremes_kernel(
+    const float* __restrict__ init, long init_capacity, int init_len,
+    SketchSource src, long n, float* __restrict__ extremes) {
+  __shared__ float lo[4], hi[4];
+  const int u = blockIdx.x, tid = threadIdx.x;
+  float a = INFINITY, b = -INFINITY;
+  for (long i = tid; i < n; i += 256) {
+    const float x = sketch_stream_at<true>(init, init_capacity, init_len, nullptr,
+                                           0, src, u, i);
+    a = fminf(a, x); b = fmaxf(b, x);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a = fminf(a, __shfl_xor(a, o));
+    b = fmaxf(b, __shfl_xor(b, o));
+  }
+  if ((tid & 63) == 0) { lo[tid >> 6] = a; hi[tid >> 6] = b; }
+  __syncthreads();
+  if (tid == 0) {
+    a = fminf(fminf(lo[0], lo[1]), fminf(lo[2], lo[3]));
+    b = fmaxf(fmaxf(hi[0], hi[1]), fmaxf(hi[2], hi[3]));
+    extremes[2 * u] = fminf(extremes[2 * u], a);
+    extremes[2 * u + 1] = fmaxf(extremes[2 * u + 1], b);
   }
 }
 
@@ -460,6 +554,186 @@ int milan_exemplar_sketch_compact(const float* src, int64_t src_capacity,
                      0, s, sorted, (long)n, (long)n, offset, dst,
                      (long)dst_capacity, (long)position, extremes);
   MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+size_t milan_exemplar_sketch_add_workspace(int n_units, int64_t supplied,
+                                           const int64_t* capacities,
+                                           int n_levels) {
+  if (n_units <= 0 || supplied <= 0 || n_levels <= 0 || !capacities) return 0;
+  int64_t caps = 0, smallest = capacities[0];
+  for (int l = 0; l < n_levels; ++l) {
+    caps += capacities[l];
+    smallest = capacities[l] < smallest ? capacities[l] : smallest;
+  }
+  smallest = smallest < 1 ? 1 : smallest;
+  // streams: level l+1 receives at most half of what level l saw, plus one
+  // element per odd-sized range
+  const int64_t ops = 2 * (supplied / smallest + 1) + 2 * n_levels + 64;
+  const int64_t floats = supplied + caps + ops + 64 * (int64_t)n_levels;
+  return align256(sizeof(SketchOp) * (size_t)ops) +
+         (size_t)n_levels * 256 + sizeof(float) * (size_t)n_units * (size_t)floats;
+}
+
+int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int hw,
+                              const int32_t* units, int n_units, int64_t first,
+                              int64_t* consumed, float* const* levels,
+                              int64_t* firstfree, const int64_t* capacities,
+                              int n_levels, const uint8_t* randbits,
+                              int64_t n_randbits, int64_t* currentbit,
+                              float* extremes, void* workspace,
+                              size_t workspace_bytes, milan_stream stream) {
+  MILAN_REQUIRE(hiddens && consumed && levels && firstfree && capacities &&
+                    randbits && currentbit && extremes && workspace,
+                MILAN_ERR_ARG, "sketch_add: null argument");
+  const int64_t total = (int64_t)batch * hw;
+  MILAN_REQUIRE(n_units > 0 && n_units <= 65535 && n_levels >= 1 && n_levels <= 64 &&
+                    first >= 0 && first <= total && hw > 0 && channels > 0,
+                MILAN_ERR_SHAPE, "sketch_add: bad sizes");
+  for (int l = 0; l < n_levels; ++l)
+    MILAN_REQUIRE(capacities[l] >= 2 && capacities[l] <= kSortCap &&
+                      firstfree[l] >= 0 && firstfree[l] <= capacities[l],
+                  MILAN_ERR_SHAPE,
+                  "sketch_add: level capacity outside [2, 8192] (use the per-op path)");
+  *consumed = 0;
+  const int64_t supplied = total - first;
+  if (supplied == 0) return 0;
+
+  // ---- play the state machine forward (runningstats.py:363-407) -------------
+  std::vector<int64_t> ff(firstfree, firstfree + n_levels), trial(n_levels);
+  std::vector<int64_t> emitted(n_levels + 1, 0);  // elements level l-1 sent to l
+  std::vector<int64_t> done(n_levels, 0);         // S_l consumed by compactions
+  std::vector<std::vector<SketchOp>> ops(n_levels);
+  std::vector<SketchOp> pending;
+  std::vector<int> pending_level;
+  int64_t bit = *currentbit, index = 0;
+  bool blocked = false;
+  while (index < supplied) {
+    if (capacities[0] - ff[0] == 0) {
+      // one _shift(): tentative, committed only if it needs neither _expand()
+      // nor more random bits than the caller's buffer still holds
+      trial = ff;
+      pending.clear(); pending_level.clear();
+      int64_t b = bit;
+      int l = 0;
+      bool ok = true;
+      while (capacities[l] - trial[l] < (l ? (capacities[l - 1] + 1) / 2 : 1)) {
+        if (l + 1 >= n_levels || b + 1 >= n_randbits) { ok = false; break; }
+        const int offset = randbits[++b] ? 1 : 0;
+        const int64_t n = trial[l];
+        const int64_t moved = (n - offset + 1) / 2;
+        pending.push_back(SketchOp{0, (int)n, offset, 0});
+        pending_level.push_back(l);
+        trial[l] = 0;
+        trial[l + 1] += moved;
+        ++l;
+      }
+      if (!ok) { blocked = true; break; }
+      for (size_t i = 0; i < pending.size(); ++i) {
+        const int pl = pending_level[i];
+        SketchOp op = pending[i];
+        op.start = (int)done[pl];
+        op.outpos = (int)emitted[pl + 1];
+        const int64_t moved = (op.n - op.offset + 1) / 2;
+        done[pl] += op.n;
+        emitted[pl + 1] += moved;
+        if (op.n > 0) ops[pl].push_back(op);
+      }
+      ff = trial;
+      bit = b;
+    }
+    const int64_t room = capacities[0] - ff[0];
+    const int64_t take = room < supplied - index ? room : supplied - index;
+    ff[0] += take;
+    index += take;
+  }
+  (void)blocked;  // the caller sees consumed < supplied and runs one _shift()
+
+  // ---- workspace ---------------------------------------------------------------
+  size_t n_ops = 0;
+  for (int l = 0; l < n_levels; ++l) n_ops += ops[l].size();
+  char* w = (char*)workspace;
+  SketchOp* d_ops = (SketchOp*)w;
+  size_t need = align256(sizeof(SketchOp) * (n_ops ? n_ops : 1));
+  std::vector<float*> wl(n_levels + 1, nullptr);
+  for (int l = 1; l < n_levels; ++l) {
+    wl[l] = (float*)(w + need);
+    need += align256(sizeof(float) * (size_t)n_units * (size_t)emitted[l]);
+  }
+  MILAN_REQUIRE(need <= workspace_bytes, MILAN_ERR_WORKSPACE,
+                "sketch_add: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_ops) {
+    std::vector<SketchOp> flat;
+    flat.reserve(n_ops);
+    for (int l = 0; l < n_levels; ++l)
+      flat.insert(flat.end(), ops[l].begin(), ops[l].end());
+    // pageable source: the runtime stages it before returning
+    MILAN_CHECK_HIP(hipMemcpyAsync(d_ops, flat.data(), sizeof(SketchOp) * n_ops,
+                                   hipMemcpyHostToDevice, s));
+  }
+  const SketchSource src{hiddens, units, channels, hw, (long)first};
+
+  // ---- level by level -----------------------------------------------------------
+  size_t at = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const size_t count = ops[l].size();
+    if (!count) continue;
+    int widest = 2;
+    for (const SketchOp& op : ops[l]) widest = op.n > widest ? op.n : widest;
+    int P = 2;
+    while (P < widest) P <<= 1;
+    int threads = P / 2;
+    threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
+    const size_t lds = sizeof(float) * (size_t)P;
+    for (size_t begin = 0; begin < count; begin += 65535u * 64u) {
+      const size_t part = count - begin < 65535u * 64u ? count - begin : 65535u * 64u;
+      if (l == 0)
+        hipLaunchKernelGGL(sketch_level_kernel<true>, dim3((unsigned)part, n_units),
+                           dim3(threads), lds, s, levels[0], (long)capacities[0],
+                           (int)firstfree[0], (const float*)nullptr, 0L, src,
+                           d_ops + at + begin, wl[1], (long)emitted[1]);
+      else
+        hipLaunchKernelGGL(sketch_level_kernel<false>, dim3((unsigned)part, n_units),
+                           dim3(threads), lds, s, levels[l], (long)capacities[l],
+                           (int)firstfree[l], (const float*)wl[l], (long)emitted[l],
+                           src, d_ops + at + begin, wl[l + 1], (long)emitted[l + 1]);
+    }
+    at += count;
+  }
+  MILAN_CHECK_HIP(hipGetLastError());
+  if (done[0] > 0)  // runningstats.py:398-399 / :415-419
+    hipLaunchKernelGGL(sketch_stream_extremes_kernel, dim3(n_units), dim3(256), 0, s,
+                       levels[0], (long)capacities[0], (int)firstfree[0], src,
+                       (long)done[0], extremes);
+
+  // ---- what is left of every stream is the level's new content --------------------
+  for (int l = 0; l < n_levels; ++l) {
+    const int64_t old = firstfree[l];
+    const int64_t length = old + (l ? emitted[l] : index);
+    const int64_t keep = length - done[l];
+    MILAN_REQUIRE(keep == ff[l], MILAN_ERR_SHAPE, "sketch_add: plan inconsistent");
+    // untouched prefix stays where it is when nothing was compacted
+    const int64_t from = done[l] > 0 ? done[l] : old;  // stream position
+    const int64_t column = done[l] > 0 ? 0 : old;
+    const int64_t n = length - from;
+    if (n <= 0) continue;
+    if (l == 0) {
+      hipLaunchKernelGGL(sketch_append_kernel, dim3(grid1(n, 64), n_units), dim3(256),
+                         0, s, hiddens, channels, hw, units,
+                         (long)(first + from - old), (long)n, levels[0],
+                         (long)capacities[0], (long)column);
+    } else {
+      MILAN_CHECK_HIP(hipMemcpy2DAsync(
+          levels[l] + column, sizeof(float) * capacities[l], wl[l] + (from - old),
+          sizeof(float) * emitted[l], sizeof(float) * n, n_units,
+          hipMemcpyDeviceToDevice, s));
+    }
+  }
+  MILAN_CHECK_HIP(hipGetLastError());
+  for (int l = 0; l < n_levels; ++l) firstfree[l] = ff[l];
+  *currentbit = bit;
+  *consumed = index;
   return 0;
 }
 

@@ -148,6 +148,7 @@ class RunningQuantile:
         self.count = 0
         self.batchcount = 0
         self._ws = None
+        self.bulk = True  # False: one launch per append / compaction
         self.lib = hip.load_library()
 
     def size(self) -> int:
@@ -203,6 +204,13 @@ class RunningQuantile:
                 'samples per unit) is not built')
         index = 0
         while index < supplied:  # runningstats.py:363-385
+            if self.bulk and max(d.shape[1] for d in self.data) <= 8192:
+                index += self._add_bulk(hiddens, batch, channels, hw, units,
+                                        index)
+                if index >= supplied:
+                    break
+                # level 0 is full and the next _shift() needs _expand() or a
+                # refill of the random bits: that one goes the per-op way
             ff = self.firstfree[0]
             available = self.data[0].shape[1] - ff
             if available == 0:
@@ -219,6 +227,33 @@ class RunningQuantile:
                     self.data[0].shape[1], ff, _stream(self.device)))
             self.firstfree[0] += copycount
             index += copycount
+
+    def _add_bulk(self, hiddens, batch, channels, hw, units, first) -> int:
+        """As many of the remaining samples as the state machine can take
+        without `_expand()` / new random bits, in one call (the control flow
+        depends on sizes only: milan_exemplar_sketch_add plays it forward on
+        the host and runs every level's compactions as one launch)."""
+        n = len(self.data)
+        caps = (ctypes.c_int64 * n)(*[d.shape[1] for d in self.data])
+        need = int(self.lib.milan_exemplar_sketch_add_workspace(
+            self.depth, batch * hw - first, caps, n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ptrs = (ctypes.c_void_p * n)(*[d.data_ptr() for d in self.data])
+        ff = (ctypes.c_int64 * n)(*self.firstfree)
+        consumed = ctypes.c_int64(0)
+        bit = ctypes.c_int64(self.currentbit)
+        with torch.cuda.device(self.device):
+            hip._check(self.lib.milan_exemplar_sketch_add(
+                hiddens.data_ptr(), batch, channels, hw, hip._ptr(units),
+                self.depth, first, ctypes.byref(consumed), ptrs, ff, caps, n,
+                self.randbits.data_ptr(), len(self.randbits), ctypes.byref(bit),
+                self.extremes.data_ptr(), self._ws.data_ptr(),
+                self._ws.numel(), _stream(self.device)))
+        self.firstfree = list(ff)
+        self.currentbit = int(bit.value)
+        return int(consumed.value)
 
     def add(self, incoming: torch.Tensor) -> None:
         """Reference contract: `incoming` (samples, units)."""

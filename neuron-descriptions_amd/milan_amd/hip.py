@@ -52,7 +52,7 @@ class Dims(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 4  # MILAN_ABI_VERSION this binding was written against
+ABI_VERSION = 5  # MILAN_ABI_VERSION this binding was written against
 
 # milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
 TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET, TRUNK_NONE = 0, 1, 2, 3
@@ -115,6 +115,12 @@ SIGNATURES = {
     'milan_exemplar_sort_workspace': (_SZ, [_I, _I64, _I]),
     'milan_exemplar_sketch_compact':
         (_I, [_P, _I64, _I64, _I, _I, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    'milan_exemplar_sketch_add_workspace':
+        (_SZ, [_I, _I64, ctypes.POINTER(_I64), _I]),
+    'milan_exemplar_sketch_add':
+        (_I, [_P, _I, _I, _I, _P, _I, _I64, ctypes.POINTER(_I64),
+              ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+              _I, _P, _I64, ctypes.POINTER(_I64), _P, _P, _SZ, _P]),
     'milan_exemplar_sketch_quantile':
         (_I, [ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
               _I, _I, _P, _F, _P, _P, _SZ, _P]),

@@ -162,3 +162,41 @@ def test_discriminative_end_to_end_on_gpu(M, G, tmp_path):
         exemplars.compute(None, None, dataset, quantile=2, image_size=16)
     with pytest.raises(ValueError, match='image_size= must be set'):
         exemplars.compute(None, None, dataset)
+
+
+@pytest.mark.parametrize('r,batch,channels,side,adds,subset', [
+    (64, 8, 16, 28, 6, False),     # 128-bit random pool: refills mid-batch
+    (3 * 1024, 4, 8, 56, 5, True),  # the class default, unit subset
+    (4096, 16, 4, 112, 3, False),  # compute()'s sketch on a conv1-sized map
+])
+def test_bulk_sketch_add_equals_per_operation_path(r, batch, channels, side,
+                                                   adds, subset):
+    """milan_exemplar_sketch_add (state machine played forward, one launch per
+    level) leaves the sketch in the state the append / compact sequence does:
+    same buffers in the same order, extremes, random-bit cursor, quantiles."""
+    hip.require_device('cuda')
+    units = (torch.tensor([5, 0, 3], dtype=torch.int32, device='cuda')
+             if subset else None)
+    sketches = []
+    for bulk in (True, False):
+        torch.manual_seed(11)
+        rq = exemplars.RunningQuantile(r=r)
+        rq.bulk = bulk
+        g = torch.Generator().manual_seed(4)
+        for i in range(adds):
+            b = batch if i != 1 else max(1, batch // 3)  # a ragged one
+            h = torch.randn(b, channels, side, side, generator=g).cuda()
+            h[0, :, 0, 0] = 7.0 + i          # ties and moving extremes
+            rq.add_hiddens(h, units)
+        sketches.append(rq)
+    fast, slow = sketches
+    assert fast.firstfree == slow.firstfree
+    assert fast.currentbit == slow.currentbit and fast.count == slow.count
+    assert torch.equal(fast.randbits, slow.randbits)
+    assert [d.shape for d in fast.data] == [d.shape for d in slow.data]
+    assert len(fast.data) > 1
+    for a, b, n in zip(fast.data, slow.data, fast.firstfree):
+        assert torch.equal(a[:, :n], b[:, :n])
+    assert torch.equal(fast.extremes, slow.extremes)
+    for q in (0.5, 0.99):
+        assert torch.equal(fast.quantiles(q), slow.quantiles(q))

@@ -58,7 +58,12 @@ def main():
         rq = exemplars.RunningQuantile(r=4096)
         t_topk = timed(lambda: topk.add_hiddens(hid), reps)
         torch.manual_seed(0)
+        for _ in range(12):  # into the many-level regime (small level-0 buffer)
+            rq.add_hiddens(hid)
         t_sketch = timed(lambda: rq.add_hiddens(hid), reps)
+        rq.bulk = False  # one launch per append / compaction, for comparison
+        t_sketch_per_op = timed(lambda: rq.add_hiddens(hid), min(reps, 3))
+        rq.bulk = True
         levels = rq.quantiles(0.99)
         # render: every unit's 15 cells from this batch's first 15 images
         k, size = 15, 224
@@ -91,8 +96,10 @@ def main():
                  'achieved_GBs': bytes_in / t_topk / 1e6,
                  'frac': bytes_in / t_topk / 1e6 / PEAK_HBM_GBS},
                 {'stage': 'tally.sketch', 'ms': t_sketch,
-                 'bound': 'hbm (append) + sort (compaction every 8192 '
-                          'samples per unit)',
+                 'bound': 'hbm (batch read once per level-0 range + once for '
+                          'the extremes) + LDS sorts; one launch per sketch '
+                          'level (milan_exemplar_sketch_add)',
+                 'ms_per_operation_path': t_sketch_per_op,
                  'achieved_GBs': 2 * bytes_in / t_sketch / 1e6,
                  'frac': 2 * bytes_in / t_sketch / 1e6 / PEAK_HBM_GBS,
                  'sketch_levels': rq.firstfree},
