@@ -360,7 +360,7 @@ def main():
     host_steps = n_steps if args.from_host_steps < 0 else args.from_host_steps
     if host_steps > 0:
         from milan_amd import ingest
-        nh = min(host_steps, n_steps, 4)  # <= 0.77 GB of pinned host memory
+        nh = min(host_steps, n_steps, 4)  # <= 3.9 GB of pinned host memory
         host = [tuple(t.cpu().pin_memory() for t in step_data[i])
                 for i in range(nh)]
         hsizes = [sizes[i % nh] for i in range(host_steps)]
