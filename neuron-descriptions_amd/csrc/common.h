@@ -43,6 +43,10 @@ enum Epilogue : int {
   EPI_BIAS_TANH = 3,      // C = tanh(acc + bias)
   EPI_BIAS_SIGMUL = 4,    // C = sigmoid(acc + bias) * aux
   EPI_BIAS_ADD = 5,       // C = acc + bias + aux
+  EPI_LSTM = 6,           // acc + bias = an LSTM's gate pre-activations, columns
+                          // gate-interleaved per 16 units ([i16 f16 g16 o16] per 64):
+                          // C = h' (ldc), C2 = c' (ldc), aux = c (ldaux), Cs =
+                          // optional split-format copy of h' (ldc); N = 4 H
 };
 
 // C[M][N] (row stride ldc) = epi( A (*) W^T + bias ), fp32 MFMA, exact f32.
@@ -86,6 +90,8 @@ struct GemmArgs {
   int debug;          // MILAN_ABLATE timing experiments (0 in production): 1 no MFMA,
                       // 2 no DMA (igemm_kernel); 4 epilogue only, 8 main loop only (split16)
   int tile_hint;      // 0 auto, 1 force 256x128x3-stage, 2 force 128x128x2-stage
+  float* C2;          // EPI_LSTM: new cell state
+  float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
 };
 
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2 };
@@ -130,6 +136,25 @@ inline GemmArgs linear_args(const float* A, long lda, const float* W,
   return g;
 }
 
+// torch's LSTM cell, gate order i, f, g, o (one definition for the pointwise
+// kernel and the fused GEMM epilogue, roundings spelled out, so that both give
+// the same bits)
+__device__ __forceinline__ void lstm_cell(float pi, float pf, float pg, float po,
+                                          float c_in, float* h, float* c) {
+  const float gi = 1.f / (1.f + expf(-pi));
+  const float gf = 1.f / (1.f + expf(-pf));
+  const float gg = tanhf(pg);
+  const float go = 1.f / (1.f + expf(-po));
+  const float c2 = __fmaf_rn(gi, gg, __fmul_rn(gf, c_in));
+  *c = c2;
+  *h = __fmul_rn(go, tanhf(c2));
+}
+// row of gate `gate` (0..3 = i, f, g, o), hidden unit u, in the gate-interleaved
+// order EPI_LSTM expects: 64-row groups [i x16 | f x16 | g x16 | o x16]
+__host__ __device__ inline int lstm_interleaved_row(int gate, int u) {
+  return (u >> 4) * 64 + gate * 16 + (u & 15);
+}
+
 // ---- packed weights ----------------------------------------------------------
 struct ConvW {
   float* w = nullptr;     // [Cout][Kp]
@@ -152,6 +177,7 @@ struct LinearW {
   float ws_inv = 1.f;
   float* b = nullptr;
   int n = 0, k = 0, kp = 0;
+  bool gate_interleaved = false;  // rows permuted for EPI_LSTM (cat weights)
 };
 
 struct Tensor {

@@ -40,10 +40,20 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, int n, int k,
   }
 }
 
+// hidden > 0: output row i holds source row (gate, unit) of the gate-interleaved
+// order (lstm_interleaved_row); 0: identity
+__device__ inline int lstm_source_row(int i, int hidden) {
+  if (!hidden) return i;
+  const int gate = (i & 63) >> 4, u = (i >> 6) * 16 + (i & 15);
+  return gate * hidden + u;
+}
 __global__ void add_vec_kernel(const float* a, const float* b, int n,
-                               float* out) {
+                               float* out, int hidden = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = a[i] + (b ? b[i] : 0.f);
+  if (i < n) {
+    const int r = lstm_source_row(i, hidden);
+    out[i] = a[r] + (b ? b[r] : 0.f);
+  }
 }
 
 static int copy_vec(milan_ctx* c, const Tensor* t, float** out, hipStream_t s) {
@@ -89,15 +99,20 @@ static int pack_linear(milan_ctx* c, const std::string& wname,
 // anyway).  Leaves out->ws null for shapes the split path does not cover.
 __global__ void cat_rows_kernel(const float* __restrict__ a, int ka,
                                 const float* __restrict__ b, int kb, int n,
-                                float* __restrict__ out) {
+                                float* __restrict__ out, int hidden) {
   const int kt = ka + kb;
   const long total = (long)n * kt;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
-    const int r = idx / kt, col = idx - (long)r * kt;
+    const int ro = idx / kt, col = idx - (long)ro * kt;
+    const int r = lstm_source_row(ro, hidden);
     out[idx] = col < ka ? a[(long)r * ka + col] : b[(long)r * kb + (col - ka)];
   }
 }
+// LSTM weights (n = 4 H, H % 16 == 0): rows are stored gate-interleaved per 16
+// hidden units so that the GEMM epilogue sees the four gates of a unit inside
+// one wave tile and applies the cell itself (EPI_LSTM) -- the (rows, 4H)
+// pre-activation matrix is never written.
 static int cat_linear(milan_ctx* c, const LinearW& a, const LinearW& b,
                       LinearW* out, hipStream_t s) {
   *out = LinearW();
@@ -109,10 +124,18 @@ static int cat_linear(milan_ctx* c, const LinearW& a, const LinearW& b,
   MILAN_TRY(dev_alloc(c, (void**)&out->b, sizeof(float) * out->n));
   const long total = (long)out->n * out->kp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  // MILAN_LSTM_FUSE=0 (read when the weights are packed) keeps the plain row
+  // order and the separate pointwise kernel, for A/B timing
+  static const bool fuse = [] {
+    const char* e = getenv("MILAN_LSTM_FUSE");
+    return !e || atoi(e) != 0;
+  }();
+  out->gate_interleaved = fuse && out->n % 64 == 0;
+  const int hidden = out->gate_interleaved ? out->n / 4 : 0;
   hipLaunchKernelGGL(cat_rows_kernel, dim3(blocks), dim3(256), 0, s, a.w, a.k, b.w,
-                     b.k, out->n, out->w);
+                     b.k, out->n, out->w, hidden);
   hipLaunchKernelGGL(add_vec_kernel, dim3((out->n + 255) / 256), dim3(256), 0, s,
-                     a.b, b.b, out->n, out->b);
+                     a.b, b.b, out->n, out->b, hidden);
   MILAN_CHECK_HIP(hipGetLastError());
   return make_split_weight(c, out->w, out->n, out->kp, &out->ws, &out->ws_inv, s);
 }
@@ -325,13 +348,10 @@ __global__ void lstm_pointwise_kernel(const float* __restrict__ gates,
     const long r = idx / H;
     const int j = idx - r * H;
     const float* g = gates + r * 4 * H;
-    const float gi = 1.f / (1.f + expf(-g[j]));
-    const float gf = 1.f / (1.f + expf(-g[H + j]));
-    const float gg = tanhf(g[2 * H + j]);
-    const float go = 1.f / (1.f + expf(-g[3 * H + j]));
-    const float c2 = gf * c_in[idx] + gi * gg;
+    float h2, c2;
+    lstm_cell(g[j], g[H + j], g[2 * H + j], g[3 * H + j], c_in[idx], &h2, &c2);
     c_out[idx] = c2;
-    h_out[idx] = go * tanhf(c2);
+    h_out[idx] = h2;
   }
 }
 
@@ -965,28 +985,41 @@ static int lin(milan_ctx* c, const float* A, long lda, const LinearW& w, float* 
   return launch_gemm(g, s);
 }
 
-// C = A1 W1^T + A2 W2^T + b1 + b2 (an LSTM's gate pre-activations).  Split
+// One LSTM layer step: (h', c') = cell(A1 W1^T + A2 W2^T + b1 + b2, c).  Split
 // mode with a concatenated weight: both operands are converted side by side
 // into one scratch matrix [A1 | A2] and multiplied by [W1 | W2] in ONE launch
-// (no second GEMM, no read-modify-write of C); otherwise two GEMMs, the second
-// accumulating into the first.
-static int lin_pair(milan_ctx* c, const float* A1, long lda1, const LinearW& w1,
-                    const float* A2, long lda2, const LinearW& w2,
-                    const LinearW& cat, float* C, int ldc, int M,
-                    hipStream_t s) {
+// whose epilogue applies the cell (gate-interleaved rows, EPI_LSTM) -- the gate
+// pre-activations never reach HBM; otherwise two GEMMs, the second accumulating
+// into the first, and the pointwise kernel.
+static int lstm_layer(milan_ctx* c, const float* A1, long lda1, const LinearW& w1,
+                      const float* A2, long lda2, const LinearW& w2,
+                      const LinearW& cat, float* gates, const float* c_in,
+                      float* h_out, float* c_out, int M, hipStream_t s) {
+  const int H = w1.n / 4;
   if (c->precision == MILAN_PRECISION_SPLIT_F16 && cat.ws && c->scratch &&
       (size_t)M * cat.k <= c->scratch_floats) {
     MILAN_TRY(launch_f32_to_split(A1, lda1, c->scratch, cat.k, M, w1.k, 1.f, s));
     MILAN_TRY(launch_f32_to_split(A2, lda2, c->scratch + w1.k, cat.k, M, w2.k,
                                   1.f, s));
-    GemmArgs g = linear_args(c->scratch, cat.k, cat.ws, cat.b, C, ldc, M, cat.n,
-                             cat.k, EPI_BIAS, c->zero);
+    GemmArgs g = linear_args(c->scratch, cat.k, cat.ws, cat.b, gates, 4 * H, M,
+                             cat.n, cat.k, EPI_BIAS, c->zero);
     g.a_split = 1;
     g.acc_scale = cat.ws_inv;
-    return launch_gemm(g, s);
+    if (cat.gate_interleaved && H % 8 == 0) {
+      g.epilogue = EPI_LSTM;
+      g.C = h_out; g.C2 = c_out; g.ldc = H;
+      g.aux = c_in; g.ldaux = H;
+      return launch_gemm(g, s);
+    }
+    MILAN_REQUIRE(!cat.gate_interleaved, MILAN_ERR_STATE, "lstm: weight layout");
+    MILAN_TRY(launch_gemm(g, s));
+  } else {
+    MILAN_TRY(lin(c, A1, lda1, w1, gates, 4 * H, M, EPI_BIAS, s));
+    MILAN_TRY(lin(c, A2, lda2, w2, gates, 4 * H, M, EPI_BIAS_ADD, s, gates, 4 * H));
   }
-  MILAN_TRY(lin(c, A1, lda1, w1, C, ldc, M, EPI_BIAS, s));
-  return lin(c, A2, lda2, w2, C, ldc, M, EPI_BIAS_ADD, s, C, ldc);
+  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)M * H)), dim3(256), 0, s,
+                     gates, c_in, M, H, h_out, c_out);
+  return 0;
 }
 
 struct LmState {  // [layers][rows][Hl]
@@ -1009,10 +1042,8 @@ static int lm_step(milan_ctx* c, const int64_t* tok, int rows, LmState& st,
     const float* cl = st.c + (long)l * st.rows * Hl;
     float* hn = nx.h + (long)l * nx.rows * Hl;
     float* cn = nx.c + (long)l * nx.rows * Hl;
-    MILAN_TRY(lin_pair(c, in, in_dim, c->lm_ih[l], hl, Hl, c->lm_hh[l],
-                       c->lm_cat[l], gates, 4 * Hl, rows, s));
-    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * Hl)),
-                       dim3(256), 0, s, gates, cl, rows, Hl, hn, cn);
+    MILAN_TRY(lstm_layer(c, in, in_dim, c->lm_ih[l], hl, Hl, c->lm_hh[l],
+                         c->lm_cat[l], gates, cl, hn, cn, rows, s));
     in = hn;
     in_dim = Hl;
   }
@@ -1158,6 +1189,7 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
   if (fused) {
     float* xs = c->scratch;                       // (rows, E+F) split
     float* hs = c->scratch + (size_t)rows * ldx;  // (rows, H) split
+    float* hs2 = b->gates;  // h' split (vocabulary GEMM); the gate matrix is unused here
     MILAN_TRY(launch_f32_to_split(h, H, hs, H, rows, H, 1.f, s));
     auto split_lin = [&](const LinearW& w, float* C, int ldc, int epi,
                          const float* aux, int ldaux) {
@@ -1181,18 +1213,29 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
     {
       // gates = [x | h] [W_ih | W_hh]^T: x from xs (k < E+F), h from hs
       const LinearW& w = c->lstm_cat;
-      GemmArgs g = linear_args(xs, ldx, w.ws, w.b, b->gates, 4 * H, rows, w.n,
-                               w.k, EPI_BIAS, c->zero);
+      // the epilogue applies the cell and writes h' in both forms (fp32 state +
+      // split operand of the vocabulary GEMM); hs is this GEMM's own A2 source,
+      // so the split copy goes to a second buffer
+      const bool cell = w.gate_interleaved;  // false only under MILAN_LSTM_FUSE=0
+      GemmArgs g = cell ? linear_args(xs, ldx, w.ws, w.b, hn, H, rows, w.n, w.k,
+                                      EPI_LSTM, c->zero, cc, H)
+                        : linear_args(xs, ldx, w.ws, w.b, b->gates, 4 * H, rows,
+                                      w.n, w.k, EPI_BIAS, c->zero);
+      if (cell) { g.C2 = cn; g.Cs = hs2; }
       g.a_split = 1;
       g.acc_scale = w.ws_inv;
       g.Cin = ldx;  // geometry of source 1
       g.A2 = hs; g.K1 = ldx; g.H2 = 1; g.W2d = 1; g.stride2 = 1;
       g.a2_pix_stride = H; g.a2_img_stride = H;
       MILAN_TRY(launch_gemm(g, s));
+      if (!cell) {
+        hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * H)),
+                           dim3(256), 0, s, b->gates, cc, rows, H, hn, cn);
+        hs2 = hs;
+        MILAN_TRY(launch_f32_to_split(hn, H, hs2, H, rows, H, 1.f, s));
+      }
     }
-    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * H)),
-                       dim3(256), 0, s, b->gates, cc, rows, H, hn, cn);
-    MILAN_TRY(launch_f32_to_split(hn, H, hs, H, rows, H, 1.f, s));
+    hs = hs2;
     MILAN_TRY(launch_gemm(split_lin(c->out, b->logits, V, EPI_BIAS, nullptr, 0), s));
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1205,10 +1248,8 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
   MILAN_TRY(lin(c, h, H, c->gate, b->x + E, ldx, rows, EPI_BIAS_SIGMUL, s, b->ctx, F));
   hipLaunchKernelGGL(embed_kernel, dim3(nblk((long)rows * E)), dim3(256), 0, s,
                      c->embedding, tok, rows, E, b->x, ldx);
-  MILAN_TRY(lin_pair(c, b->x, ldx, c->lstm_ih, h, H, c->lstm_hh, c->lstm_cat,
-                     b->gates, 4 * H, rows, s));
-  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((long)rows * H)), dim3(256),
-                     0, s, b->gates, cc, rows, H, hn, cn);
+  MILAN_TRY(lstm_layer(c, b->x, ldx, c->lstm_ih, h, H, c->lstm_hh, c->lstm_cat,
+                       b->gates, cc, hn, cn, rows, s));
   MILAN_TRY(lin(c, hn, H, c->out, b->logits, V, rows, EPI_BIAS, s));
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;

@@ -258,6 +258,75 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
     }
   };
 
+  // (4) LSTM cell on gate-interleaved columns: the wave's 64 columns are
+  // [i x16 | f x16 | g x16 | o x16] of hidden units col0/4 .. col0/4 + 15; a lane
+  // takes the four gates of 4 consecutive units from the staged tile.
+  auto epilogue_lstm = [&]() {
+    const int q4 = (lane & 3) * 4;
+    const int u = (col0 >> 2) + q4;  // first of this lane's 4 hidden units
+    const bool n_ok = col0 < g.N;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate)
+      bias4[gate] = (g.bias && n_ok)
+                        ? *reinterpret_cast<const f32x4*>(g.bias + col0 + gate * 16 + q4)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cin[2][2];
+    auto load_c = [&](int i, f32x4 (&c)[2]) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int m = row0 + i * 32 + it * 16 + (lane >> 2);
+        c[it] = (m < g.M && n_ok)
+                    ? *reinterpret_cast<const f32x4*>(g.aux + (long)m * g.ldaux + u)
+                    : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    load_c(0, cin[0]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i + 1 < TM) load_c(i + 1, cin[(i + 1) & 1]);
+      to_stage(i);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + (lane >> 2);
+        const int m = row0 + i * 32 + row;
+        f32x4 p[4];
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate)
+          p[gate] = *reinterpret_cast<const f32x4*>(stage_out + row * SROW +
+                                                    gate * 16 + q4) + bias4[gate];
+        if (m < g.M && n_ok) {
+          f32x4 h4, c4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float hh, cc;
+            lstm_cell(p[0][e], p[1][e], p[2][e], p[3][e], cin[i & 1][it][e], &hh, &cc);
+            h4[e] = hh; c4[e] = cc;
+          }
+          *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + u) = h4;
+          *reinterpret_cast<f32x4*>(g.C2 + (long)m * g.ldc + u) = c4;
+          if (g.Cs) {
+            // split format: 8 channels = 32 B [hi x8 | lo x8]; this lane owns
+            // one half (4 channels) of its group
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = fminf(fmaxf(h4[e], -65504.f), 65504.f);
+              const _Float16 hh = (_Float16)x;
+              hi[e] = hh;
+              lo[e] = (_Float16)(x - (float)hh);
+            }
+            char* base = reinterpret_cast<char*>(g.Cs + (long)m * g.ldc) +
+                         (u >> 3) * 32 + ((u >> 2) & 1) * 8;
+            *reinterpret_cast<f16x4*>(base) = hi;
+            *reinterpret_cast<f16x4*>(base + 16) = lo;
+          }
+        }
+      }
+    }
+  };
+
   // (3) scalar fallback (unaligned fp32 outputs of odd-sized test models).
   auto epilogue_scalar = [&](auto epi_tag) {
     constexpr int EPI = decltype(epi_tag)::value;
@@ -297,7 +366,9 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
       default: fn(std::integral_constant<int, EPI_BIAS>{}); break;
     }
   };
-  if (g.out_mode == OUT_SPLIT8) {
+  if (g.epilogue == EPI_LSTM) {
+    epilogue_lstm();
+  } else if (g.out_mode == OUT_SPLIT8) {
     // only the conv epilogues exist in split form
     switch (g.epilogue) {
       case EPI_BIAS_RELU: epilogue_split8(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
@@ -1344,7 +1415,16 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     g.debug = dbg;  // 1: skip MFMA phase, 2: skip DMA (timing experiments only)
   }
   // pick the epilogue form
-  if (g.out_split || g.aux_split) {
+  if (g.epilogue == EPI_LSTM) {
+    MILAN_REQUIRE(!g.out_split && !g.aux_split && g.N % 64 == 0 && g.ldc % 8 == 0 &&
+                      g.ldaux % 4 == 0 && g.C && g.C2 && g.aux && aligned16(g.C) &&
+                      aligned16(g.C2) && aligned16(g.aux) &&
+                      (g.Cs == nullptr || aligned16(g.Cs)) &&
+                      (g.bias == nullptr || aligned16(g.bias)),
+                  MILAN_ERR_SHAPE, "gemm: bad LSTM epilogue geometry (N=%d ldc=%d)",
+                  g.N, g.ldc);
+    g.out_mode = OUT_VEC4;
+  } else if (g.out_split || g.aux_split) {
     MILAN_REQUIRE(g.out_split && g.N % 8 == 0 && g.ldc % 8 == 0 && aligned16(g.C) &&
                       (g.bias == nullptr || aligned16(g.bias)) &&
                       (g.aux == nullptr ||

@@ -178,8 +178,16 @@ class QuantileSketch:
                 self.firstfree[index] = scrunched.shape[1]
         return cap > 0
 
-    def quantiles(self, q: float) -> torch.Tensor:
-        """`quantiles(q)` for one scalar q -> (depth,) float32."""
+    def quantiles(self, q: float, stable: bool = False) -> torch.Tensor:
+        """`quantiles(q)` for one scalar q -> (depth,) float32.
+
+        `stable=False` is the reference's call, `torch.sort(summary, dim=-1)`:
+        NOT a stable sort (torch's CPU sort reorders equal keys once a row has
+        more than ~16 elements; its CUDA sort orders them yet another way), so
+        when equal samples sit on different levels -- post-ReLU zeros -- the
+        order of their WEIGHTS, and with it the interpolated quantile at the
+        edge of the run, is unspecified upstream.  `stable=True` keeps equal
+        samples in level order, which is what the HIP kernel defines."""
         if self.firstfree[0]:
             d0 = self.data[0][:, :self.firstfree[0]]
             self._update_extremes(d0.min(dim=1)[0], d0.max(dim=1)[0])
@@ -193,7 +201,7 @@ class QuantileSketch:
             summary[:, index:index + ff] = self.data[level][:, :ff]
             weights[index:index + ff] = 2.0**level
             index += ff
-        summary, order = torch.sort(summary, dim=-1)  # stable on CPU
+        summary, order = torch.sort(summary, dim=-1, stable=stable)
         weights = weights[order.view(-1)].view(order.shape)
         summary = torch.cat(
             [self.extremes[:, :1], summary, self.extremes[:, 1:]], dim=-1)
@@ -289,9 +297,11 @@ def compute(compute_topk_and_quantile: Callable,
             quantile: float = 0.99,
             output_size: int = 224,
             batch_size: int = 128,
-            mul=(255.0,) * 3, add=(0.0,) * 3):
+            mul=(255.0,) * 3, add=(0.0,) * 3,
+            stable_ties: bool = False):
     """`compute` (src/exemplars/compute.py:27-246) minus file output.
-    Returns dict(images, masks, masked, ids, activations, levels)."""
+    Returns dict(images, masks, masked, ids, activations, levels).
+    `stable_ties`: see QuantileSketch.quantiles."""
     if units is not None:
         units = sorted(units)
     topk, sketch = TopK(k), QuantileSketch()
@@ -303,7 +313,7 @@ def compute(compute_topk_and_quantile: Callable,
             pooled, activations = pooled[:, units], activations[:, units]
         topk.add(pooled)
         sketch.add(activations)
-    levels = sketch.quantiles(quantile)
+    levels = sketch.quantiles(quantile, stable=stable_ties)
     acts_top, ids = topk.result()
     n_units = ids.shape[0]
     size = (output_size, output_size)

@@ -3,6 +3,7 @@
 vocabulary sizes, trunk kinds, MI on/off and temperatures -- the shapes nobody
 thought to write a dedicated test for (odd image sizes, V not a multiple of 4,
 beam == V, k == 1, a single neuron, widths that defeat the split-f16 path)."""
+import os
 import random
 
 import pytest
@@ -40,7 +41,11 @@ def draw(seed):
         mask_kind=r.choice(['u8', 'float01', 'soft']))
 
 
-@pytest.mark.parametrize('seed', range(36))
+# MILAN_FUZZ_SEEDS=<n> widens the campaign (a 400-seed run is in DESIGN.md)
+N_SEEDS = int(os.environ.get('MILAN_FUZZ_SEEDS', '36'))
+
+
+@pytest.mark.parametrize('seed', range(N_SEEDS))
 def test_fuzz_encode_and_decode(seed):
     dev = hip.require_device('cuda')
     p = draw(1000 + seed)
