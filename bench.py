@@ -145,25 +145,39 @@ def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
                  rerank, split, pool_bytes_img, step_ms):
     """north_star: achieved fraction of the HBM / MFMA roofline per stage."""
     peak_tf = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    mfma_per_product = 3.0 if split else 1.0
     out = []
 
     def mfma(name, keys, label, flops_override=None):
         ms = sum(stages[k]['region_ms'] for k in keys)
         gemm_ms = sum(stages[k]['gemm_ms'] for k in keys)
         flops = sum(stages[k]['gemm_flops'] for k in keys)
+        gbytes = sum(stages[k].get('gemm_bytes', 0.0) for k in keys)
         if flops_override is not None:
             flops = flops_override
         if ms <= 0:
             return
         ach = flops / (ms * 1e-3) / 1e12
-        out.append({
-            'stage': name, 'what': label, 'bound': 'mfma',
+        # the same stage against the other roof: algorithmic HBM bytes of its
+        # GEMM launches (each operand once) over the stage time.  A stage is
+        # labelled by the roof it sits closer to (MFMA issue = 3 instructions
+        # per product in split mode).
+        hbm_gbs = gbytes / (ms * 1e-3) / 1e9
+        issue = ach * mfma_per_product / peak_tf
+        entry = {
+            'stage': name, 'what': label,
+            'bound': 'hbm' if hbm_gbs / PEAK_HBM_GBS > issue else 'mfma',
             'ms_per_step': ms / n_steps,
             'gemm_ms_per_step': gemm_ms / n_steps,
             'achieved': ach, 'peak': peak_tf, 'unit': 'TFLOP/s',
             'frac': ach / peak_tf,
+            'mfma_issue_frac': issue,
+            'hbm_achieved_GBs': hbm_gbs,
+            'hbm_frac': hbm_gbs / PEAK_HBM_GBS,
+            'algorithmic_gemm_GB_per_step': gbytes / n_steps / 1e9,
             'share_of_step': ms / n_steps / step_ms,
-        })
+        }
+        out.append(entry)
 
     def hbm(name, key, label, bytes_per_image):
         ms = stages[key]['region_ms']

@@ -236,8 +236,10 @@ int milan_profile_read(double* gemm_ms, double* gemm_flops,
  * HBM/MFMA roofline reported per stage").  While profiling is enabled every
  * stage region of the hot path is also bracketed by two HIP events and every
  * GEMM record carries the stage it ran in.  `table` receives
- * MILAN_STAGE_COUNT rows of 5 doubles: region ms (sum over calls), region
- * count, GEMM ms inside the stage, GEMM algorithmic FLOPs, GEMM launches. */
+ * MILAN_STAGE_COUNT rows of 6 doubles: region ms (sum over calls), region
+ * count, GEMM ms inside the stage, GEMM algorithmic FLOPs, GEMM launches, GEMM
+ * algorithmic HBM bytes (every operand of a launch crossing HBM once: visited
+ * input pixels, weights, residual, output -- what bounds the small-K layers). */
 enum milan_stage {
   MILAN_STAGE_OTHER = 0,
   MILAN_STAGE_ENC_INPUT = 1,     /* mask pyramid lists + u8 -> normalised input
@@ -255,7 +257,7 @@ enum milan_stage {
   MILAN_STAGE_DEC_LM = 11,       /* LM scoring of the beams + rerank select   */
   MILAN_STAGE_COUNT = 12
 };
-int milan_profile_read_stages(double* table /* [MILAN_STAGE_COUNT][5] */);
+int milan_profile_read_stages(double* table /* [MILAN_STAGE_COUNT][6] */);
 
 /* ---- exemplar computation ---------------------------
  * The stage that WRITES the images.npy / masks.npy this path reads

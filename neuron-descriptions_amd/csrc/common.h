@@ -106,7 +106,7 @@ int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
 int gemm_profile_enable(int enable);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, long long* launches);
-int profile_read_stages(double* table /* [MILAN_STAGE_COUNT][5] */);
+int profile_read_stages(double* table /* [MILAN_STAGE_COUNT][6] */);
 // RAII bracket of one stage region on a stream: labels the GEMM launches made
 // inside it and, while profiling is on, times the region with two HIP events.
 class StageScope {

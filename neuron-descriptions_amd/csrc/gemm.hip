@@ -1245,7 +1245,33 @@ struct ProfRec {
   int stage = 0;
   bool gemm = false;
   double flops = 0.0;
+  double bytes = 0.0;  // algorithmic HBM bytes of a GEMM launch
 };
+
+// What a launch has to move if every operand crosses HBM exactly once: the
+// input pixels it reads (whole images for a k x k conv, the visited pixels for
+// a 1x1), the second source, the weights, the residual / multiplicand and the
+// output (fp32 and split format are both 4 B per element).
+static double gemm_algorithmic_bytes(const GemmArgs& g) {
+  const double M = g.M, N = g.N;
+  const int k1 = g.A2 ? g.K1 : g.K;
+  double a;
+  if (g.KH == 1 && g.KW == 1) {
+    a = M * (double)k1;
+  } else {
+    const double images = M / ((double)g.Ho * g.Wo);
+    a = images * (double)g.H * g.Wd * g.Cin;
+  }
+  if (g.A2) a += M * (double)(g.K - g.K1);
+  double c = M * N;
+  double aux = g.aux ? M * N : 0.0;
+  if (g.epilogue == EPI_LSTM) {  // N = 4 H: c read; h', c' (and split h') written
+    const double H = N / 4;
+    c = M * H * (g.Cs ? 3.0 : 2.0);
+    aux = M * H;
+  }
+  return 4.0 * (a + (double)g.N * g.Kp + c + aux);
+}
 struct Profiler {
   bool on = false;
   std::vector<ProfRec> rec;
@@ -1280,7 +1306,7 @@ StageScope::StageScope(int stage, hipStream_t s) : stream_(s) {
   if (!g_prof.on) return;
   ProfRec* r = prof_next();
   if (!r) return;
-  r->stage = stage; r->gemm = false; r->flops = 0.0;
+  r->stage = stage; r->gemm = false; r->flops = 0.0; r->bytes = 0.0;
   idx_ = (long)(g_prof.used - 1);
   (void)hipEventRecord(r->a, s);
 }
@@ -1311,14 +1337,14 @@ int gemm_profile_read(double* ms, double* flops, long long* launches) {
 // table[stage][0..4] = region ms, region count, gemm ms, gemm flops, gemm launches
 int profile_read_stages(double* table) {
   MILAN_CHECK_HIP(hipDeviceSynchronize());
-  for (int i = 0; i < MILAN_STAGE_COUNT * 5; ++i) table[i] = 0.0;
+  for (int i = 0; i < MILAN_STAGE_COUNT * 6; ++i) table[i] = 0.0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     const ProfRec& r = g_prof.rec[i];
     if (r.stage < 0 || r.stage >= MILAN_STAGE_COUNT) continue;
     float t = 0.f;
     MILAN_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
-    double* row = table + r.stage * 5;
-    if (r.gemm) { row[2] += t; row[3] += r.flops; row[4] += 1.0; }
+    double* row = table + r.stage * 6;
+    if (r.gemm) { row[2] += t; row[3] += r.flops; row[4] += 1.0; row[5] += r.bytes; }
     else { row[0] += t; row[1] += 1.0; }
   }
   return 0;
@@ -1555,9 +1581,12 @@ int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     e->stage = g_prof.stage;
     e->gemm = true;
     e->flops = 0.0;
-    for (int i = 0; i < 2; ++i)
+    e->bytes = 0.0;
+    for (int i = 0; i < 2; ++i) {
       e->flops += 2.0 * (double)p.g[i].M * (double)p.g[i].N *
                   (double)(p.g[i].flop_k > 0 ? p.g[i].flop_k : p.g[i].K);
+      e->bytes += gemm_algorithmic_bytes(p.g[i]);
+    }
     MILAN_CHECK_HIP(hipEventRecord(e->a, s));
   }
   hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(NT), lds, s, p);
@@ -1581,6 +1610,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
   e->stage = g_prof.stage;
   e->gemm = true;
   e->flops = 2.0 * (double)g.M * (double)g.N * (double)(g.flop_k > 0 ? g.flop_k : g.K);
+  e->bytes = gemm_algorithmic_bytes(g);
   MILAN_CHECK_HIP(hipEventRecord(e->a, s));
   const int r = launch_gemm_impl(g, s);
   MILAN_CHECK_HIP(hipEventRecord(e->b, s));

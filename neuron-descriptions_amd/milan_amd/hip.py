@@ -704,11 +704,13 @@ STAGES = ('other', 'enc_input', 'enc_stem', 'enc_stem_tail', 'enc_layer1',
 
 def profile_read_stages() -> Dict[str, Dict[str, float]]:
     """Per-stage HIP-event timings since profile_enable(True): region ms and
-    count, plus the GEMM ms / algorithmic FLOPs / launches inside the stage."""
-    table = (ctypes.c_double * (len(STAGES) * 5))()
+    count, plus the GEMM ms / algorithmic FLOPs / launches / algorithmic HBM
+    bytes inside the stage."""
+    table = (ctypes.c_double * (len(STAGES) * 6))()
     _check(load_library().milan_profile_read_stages(table))
-    keys = ('region_ms', 'regions', 'gemm_ms', 'gemm_flops', 'gemm_launches')
-    return {name: dict(zip(keys, table[i * 5:i * 5 + 5]))
+    keys = ('region_ms', 'regions', 'gemm_ms', 'gemm_flops', 'gemm_launches',
+            'gemm_bytes')
+    return {name: dict(zip(keys, table[i * 6:i * 6 + 6]))
             for i, name in enumerate(STAGES)}
 
 
