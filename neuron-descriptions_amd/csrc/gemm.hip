@@ -639,13 +639,15 @@ __device__ __forceinline__ int xcd_tile(int b, int T) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int STAGES, int SHAPE>
+template <int BM, int BN, int STAGES, int SHAPE, int TMW = 4>
 __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
                                              int tile_n) {
   constexpr int BK = 16;
-  constexpr int TM = 4, TN = 2;               // wave tile 128 x 64
+  constexpr int TM = TMW, TN = 2;             // wave tile (TM*32) x 64: 128 x 64,
+                                              // or 64 x 64 for the N = 64 layers
+  constexpr int WROWS = TM * 32;
   constexpr int WAVES_N = BN / 64;
-  constexpr int NT = (BM / 128) * WAVES_N * 64;
+  constexpr int NT = (BM / WROWS) * WAVES_N * 64;
   constexpr int LROWS = NT / 4;               // rows per loader pass
   constexpr int A_ITERS = BM / LROWS, B_ITERS = BN / LROWS;
   constexpr int LOADS = A_ITERS + B_ITERS;
@@ -760,7 +762,7 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   int aoff[TM], boff[TN], aswz[TM], bswz[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int row = wm * 128 + i * 32 + frow;
+    const int row = wm * WROWS + i * 32 + frow;
     aoff[i] = row * BK;
     aswz[i] = (row >> 2) & 3;
   }
@@ -868,7 +870,7 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
     if (t == 123.456f) g.C[0] = t;
     return;
   }
-  run_epilogue<TM, TN>(g, acc, smem, wave, lane, tile_m * BM + wm * 128,
+  run_epilogue<TM, TN>(g, acc, smem, wave, lane, tile_m * BM + wm * WROWS,
                        tile_n * BN + wn * 64);
 }
 
@@ -878,6 +880,16 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
   const int tile = xcd_tile(blockIdx.x, tiles_m * tiles_n);
   const int tile_m = tile / tiles_n;
   split16_tile<BM, BN, STAGES, SHAPE>(g, tile_m, tile - tile_m * tiles_n);
+}
+
+// The same pipeline with 64 x 64 wave tiles (4 waves per 256 x 64 block, two
+// blocks per CU): the N = 64 layers of layer1.
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_split16_tm2_kernel(
+    GemmArgs g, int tiles_m, int tiles_n) {
+  const int tile = xcd_tile(blockIdx.x, tiles_m * tiles_n);
+  const int tile_m = tile / tiles_n;
+  split16_tile<BM, BN, STAGES, 0, 2>(g, tile_m, tile - tile_m * tiles_n);
 }
 
 // Two independent problems in ONE launch, their tiles interleaved in proportion
@@ -1372,6 +1384,27 @@ static int launch_split16_impl(const GemmArgs& g, hipStream_t s) {
 }
 
 template <int BM, int BN, int STAGES>
+static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  constexpr int NT = (BM / 64) * (BN / 64) * 64;
+  size_t lds = size_t(STAGES) * (BM + BN) * 16 * sizeof(float);
+  const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
+  if (lds < stage_bytes) lds = stage_bytes;
+  auto kern = igemm_split16_tm2_kernel<BM, BN, STAGES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kern),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, g, tiles_m,
+                     tiles_n);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int BM, int BN, int STAGES>
 static int launch_split16(const GemmArgs& g, hipStream_t s) {
   static int shape = -1;
   if (shape < 0) { const char* e = getenv("MILAN_SCHED"); shape = e ? atoi(e) : 0; }
@@ -1487,6 +1520,14 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     // (N <= 64 on the split16 pipeline -- 512x64x3 / 256x64x4 tiles -- measured
     // 10-20 % SLOWER in round 2: these layers are bound by the L2 -> LDS operand
     // traffic of a 64-column tile, not by the pipeline depth.)
+    // N <= 64: the k x k convs (layer1's 3x3) run on the split16 pipeline with
+    // 64 x 64 wave tiles (256x64 block, 3-deep ring, 2 blocks per CU): round 2,
+    // same-box A/B: l1.x.c2 10.6 -> 9.7 ms per pass.  The 1x1 layers measured
+    // 3-8 % SLOWER on it (and a 128x64 block slower still), so they stay on the
+    // 2-stage kernel; tile_hint 6 / 10 force either.
+    if (g.N <= 64 && g.tile_hint != 10 && !g.A2 &&
+        (g.tile_hint == 6 || (g.tile_hint == 0 && g.KH * g.KW > 1)))
+      return launch_split16_tm2<256, 64, 3>(g, s);
     if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
     // 3x3 / stride 1 with the chunk-major weight copy: input strip in LDS
     if (g.W3 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.A2 &&
