@@ -553,6 +553,7 @@ __global__ __launch_bounds__(256) void row_select_kernel(
 // per thread); LDS holds only reduction scratch and the <= 256 winners.  Same
 // results as row_select_kernel (same float operations, same tie rule).
 constexpr int kRowRegs = 24;
+constexpr int kGatherCap = 512;
 
 __device__ inline float funkey(unsigned key) {
   return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256) void row_select_reg_kernel(
     const float* __restrict__ logits, const float* __restrict__ lm_logits,
     float lambda, int V, int k, const int64_t* __restrict__ last_tok, int stop,
     float* __restrict__ cand_v, int* __restrict__ cand_i,
-    float* __restrict__ pred_out, long pred_stride) {
+    float* __restrict__ pred_out, long pred_stride, int rank_select) {
   __shared__ float red[8];
   __shared__ unsigned scratch[528];
   const int r = blockIdx.x, tid = threadIdx.x;
@@ -656,6 +657,70 @@ __global__ __launch_bounds__(256) void row_select_reg_kernel(
       out_v[0] = funkey(hi);
     }
     return;
+  }
+  // Exact top-k without a search over the key range.  A lower bound T0 that is
+  // itself close to the k-th largest element comes from the per-thread maxima
+  // (see below); the few elements >= T0 are gathered and each one's rank (key
+  // descending, index ascending among equals: the order the threshold path
+  // produces) is counted against the others -- ranks < k are the answer, already
+  // in output order.  One barrier-free wave pass and two LDS passes instead of
+  // ~25 bisection rounds with two barriers each.  Falls through to the threshold
+  // path when a wave holds fewer than ceil(k/4) elements or the gather overflows
+  // (long runs of equal log-probs).
+  {
+    __shared__ unsigned gk[kGatherCap];
+    __shared__ float gp[kGatherCap];
+    __shared__ int gi[kGatherCap];
+    __shared__ unsigned wave_t[4], gcount;
+    unsigned tmax = 0u;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) tmax = max(tmax, key[j]);  // invalid = 0
+    // T0 = min over the 4 waves of the wave's m-th largest thread maximum,
+    // m = ceil(k / 4): every wave then holds >= m elements >= T0, >= k in all.
+    // The rank of a lane's maximum inside its wave needs no LDS (readlane).
+    const int m_need = (k + 3) >> 2;
+    const int lane = tid & 63;
+    int rank = 0;
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+      const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)tmax, u);
+      rank += (m > tmax) || (m == tmax && u < lane);
+    }
+    if (tid == 0) gcount = 0u;
+    if (rank == m_need - 1) wave_t[tid >> 6] = rank_select ? tmax : 0u;
+    __syncthreads();
+    const unsigned t0s = min(min(wave_t[0], wave_t[1]), min(wave_t[2], wave_t[3]));
+    const unsigned T0 = t0s;
+    if (T0 != 0u) {
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < kRowRegs; ++j) c += key[j] >= T0;  // invalid keys are 0 < T0
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)c;
+      __syncthreads();
+      const int total = (int)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+      if (total <= kGatherCap) {  // block-uniform
+#pragma unroll
+        for (int j = 0; j < kRowRegs; ++j)
+          if (key[j] >= T0) {
+            const unsigned q = atomicAdd(&gcount, 1u);
+            gk[q] = key[j]; gp[q] = p[j]; gi[q] = tid + 256 * j;
+          }
+        __syncthreads();
+        for (int c0 = tid; c0 < total; c0 += 256) {
+          const unsigned mk = gk[c0];
+          const int mi = gi[c0];
+          int r2 = 0;
+          for (int u = 0; u < total; ++u) {
+            const unsigned ok = gk[u];
+            r2 += (ok > mk) || (ok == mk && gi[u] < mi);
+          }
+          if (r2 < k) { out_v[r2] = gp[c0]; out_i[r2] = mi; }
+        }
+        return;
+      }
+      __syncthreads();
+    }
   }
   // largest T with count(key >= T) >= k   (count(key >= lo) = V >= k)
   for (int it = 0; it < 32 && lo < hi; ++it) {
@@ -1265,9 +1330,14 @@ static int launch_row_select(const float* logits, const float* lm_logits,
   if (V <= kRowRegs * 256 && k <= 256 && (k <= 1 || k <= V)) {
     // ties straddling the k-th value are resolved for up to 16 picks in the
     // register kernel; larger tie groups are impossible for distinct logits
+    // MILAN_ROW_SELECT=threshold keeps the key-bisection path (A/B timing)
+    static const int rank_select = [] {
+      const char* e = getenv("MILAN_ROW_SELECT");
+      return (e && e[0] == 't') ? 0 : 1;
+    }();
     hipLaunchKernelGGL(row_select_reg_kernel, dim3(rows), dim3(256), 0, s,
                        logits, lm_logits, lambda, V, k, last_tok, stop, cand_v,
-                       cand_i, pred_out, pred_stride);
+                       cand_i, pred_out, pred_stride, rank_select);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   }

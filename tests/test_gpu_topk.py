@@ -52,3 +52,29 @@ def test_topk_matches_torch_over_vocab_sizes(nv, k):
                                atol=1e-3)
     assert torch.equal(out['beam_tokens'].cpu()[:, :, :want_t.shape[2]], want_t)
     ctx.close()
+
+
+@pytest.mark.parametrize('group,k', [(30, 50), (7, 50), (100, 16), (2, 120)])
+def test_runs_of_equal_logits_straddling_the_kth_value(group, k):
+    """Row-independent logits in runs of `group` equal values (index // group
+    decides the value): the top-k is exactly token ids 0..k-1 in order -- the
+    k-th value's run is cut at its lowest indices -- at the real vocabulary
+    size, through the register kernel's rank-count path (and, for long runs,
+    its threshold fallback)."""
+    nv = 5000
+    sd = synthetic.decoder_state_dict(nv + 4, feature_size=244, hidden_size=64,
+                                      embedding_size=16, lm_hidden_size=64,
+                                      lm_embedding_size=16, seed=9)
+    sd['output.1.weight'].zero_()
+    sd['output.1.bias'].copy_(-(torch.arange(nv + 4) // group).float() * 0.25)
+    ctx = hip.Context(hip.make_dims(sd, nv), sd, 'cuda')
+    feats = torch.rand(3, 5, 244)
+    for precision in ('f32', 'split_f16'):
+        ctx.set_precision(precision)
+        out = ctx.decode(feats, hip.BEAM, 1, k, False, 0.2)
+        bt = out['beam_tokens'].cpu()[:, :, 0]
+        assert bt.eq(torch.arange(k)).all(), (precision, bt[0])
+        want = torch.log_softmax(sd['output.1.bias'], 0)[:k]
+        torch.testing.assert_close(out['beam_scores'].cpu(),
+                                   want.expand(3, k), rtol=1e-5, atol=1e-5)
+    ctx.close()
