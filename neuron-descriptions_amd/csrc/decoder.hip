@@ -414,6 +414,8 @@ __device__ inline void block_topk(float* vals, int n, int k, float* out_v,
 // key (<= 32 block-wide counts), the winners are gathered and a bitonic sort
 // orders them by (value desc, index asc) -- the tie rule of the oracle.  About
 // 10x faster than k rounds of block argmax for k = 50, V = 5004.
+constexpr int kGatherCap = 512;  // rank-count top-k: gathered candidates
+
 __device__ inline unsigned fkey(float x) {
   const unsigned u = __float_as_uint(x);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -427,6 +429,59 @@ __device__ inline void block_topk_fast(const float* vals, int n, int k,
   float* cv = reinterpret_cast<float*>(scratch + 8);      // [256]
   int* ci = reinterpret_cast<int*>(scratch + 8 + 256);    // [256]
   const int tid = threadIdx.x;
+  {
+    // Rank counting first (see row_select_reg_kernel): T0 = min over the waves
+    // of the wave's ceil(k/4)-th largest per-thread maximum bounds the k-th
+    // value from below; the elements >= T0 are gathered and ranked (key desc,
+    // index asc).  The key-bisection path below is the fallback.
+    __shared__ unsigned gk[kGatherCap];
+    __shared__ int gi[kGatherCap];
+    __shared__ unsigned wave_t[4], gcount;
+    unsigned tmax = 0u;  // keys of real values are > 0
+    for (int i = tid; i < n; i += 256) tmax = max(tmax, fkey(vals[i]));
+    const int lane = tid & 63;
+    int rank = 0;
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+      const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)tmax, u);
+      rank += (m > tmax) || (m == tmax && u < lane);
+    }
+    __syncthreads();  // previous users of the shared arrays are done
+    if (tid == 0) gcount = 0u;
+    if (rank == ((k + 3) >> 2) - 1) wave_t[tid >> 6] = tmax;
+    __syncthreads();
+    const unsigned T0 = min(min(wave_t[0], wave_t[1]), min(wave_t[2], wave_t[3]));
+    if (T0 != 0u) {
+      int c = 0;
+      for (int i = tid; i < n; i += 256) c += fkey(vals[i]) >= T0;
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)c;
+      __syncthreads();
+      const int total = (int)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+      if (total <= kGatherCap) {  // block-uniform
+        for (int i = tid; i < n; i += 256) {
+          const unsigned key = fkey(vals[i]);
+          if (key >= T0) {
+            const unsigned q = atomicAdd(&gcount, 1u);
+            gk[q] = key; gi[q] = i;
+          }
+        }
+        __syncthreads();
+        for (int c0 = tid; c0 < total; c0 += 256) {
+          const unsigned mk = gk[c0];
+          const int mi = gi[c0];
+          int r2 = 0;
+          for (int u = 0; u < total; ++u) {
+            const unsigned ok = gk[u];
+            r2 += (ok > mk) || (ok == mk && gi[u] < mi);
+          }
+          if (r2 < k) { out_v[r2] = vals[mi]; out_i[r2] = mi; }
+        }
+        return;
+      }
+      __syncthreads();
+    }
+  }
   unsigned lo = 0u, hi = 0xFFFFFFFFu;  // invariant: count(key >= lo) >= k
   for (int it = 0; it < 32 && lo < hi; ++it) {
     const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);
@@ -553,7 +608,6 @@ __global__ __launch_bounds__(256) void row_select_kernel(
 // per thread); LDS holds only reduction scratch and the <= 256 winners.  Same
 // results as row_select_kernel (same float operations, same tie rule).
 constexpr int kRowRegs = 24;
-constexpr int kGatherCap = 512;
 
 __device__ inline float funkey(unsigned key) {
   return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
