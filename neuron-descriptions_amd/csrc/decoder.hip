@@ -1020,10 +1020,26 @@ __global__ __launch_bounds__(256) void lm_accumulate_kernel(
   const int r = blockIdx.x, tid = threadIdx.x;
   const float* x = logits + (long)r * V;
   float mx = -INFINITY;
-  for (int i = tid; i < V; i += 256) mx = fmaxf(mx, x[i]);
-  mx = block_max(mx, red);
   float s = 0.f;
-  for (int i = tid; i < V; i += 256) s += expf(x[i] - mx);
+  if (V <= kRowRegs * 256) {
+    // the row is read once and stays in registers between the two passes (same
+    // operations in the same order as the streaming form below)
+    float p[kRowRegs];
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) {
+      const int i = tid + 256 * j;
+      p[j] = i < V ? x[i] : -INFINITY;
+      mx = fmaxf(mx, p[j]);
+    }
+    mx = block_max(mx, red);
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j)
+      if (tid + 256 * j < V) s += expf(p[j] - mx);
+  } else {
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, red);
+    for (int i = tid; i < V; i += 256) s += expf(x[i] - mx);
+  }
   s = block_sum(s, red);
   if (tid == 0) {
     const int64_t in = seqs[(long)r * lds + t], tgt = seqs[(long)r * lds + t + 1];
