@@ -678,16 +678,74 @@ __global__ __launch_bounds__(256) void row_select_reg_kernel(
     return;
   }
   unsigned key[kRowRegs];
-  unsigned kmax = 0u, kmin = 0xFFFFFFFFu;
 #pragma unroll
-  for (int j = 0; j < kRowRegs; ++j) {
-    const bool ok = tid + 256 * j < V;
-    key[j] = ok ? fkey(p[j]) : 0u;
-    if (ok) { kmax = max(kmax, key[j]); kmin = min(kmin, key[j]); }
-  }
+  for (int j = 0; j < kRowRegs; ++j)
+    key[j] = tid + 256 * j < V ? fkey(p[j]) : 0u;
   unsigned* cnt = scratch;
   float* cv = reinterpret_cast<float*>(scratch + 8);
   int* ci = reinterpret_cast<int*>(scratch + 8 + 256);
+  // Exact top-k without a search over the key range.  A lower bound T0 that is
+  // itself close to the k-th largest element comes from the per-thread maxima
+  // (see below); the few elements >= T0 are gathered and each one's rank (key
+  // descending, index ascending among equals: the order the threshold path
+  // produces) is counted against the others -- ranks < k are the answer, already
+  // in output order.  One barrier-free wave pass and two LDS passes instead of
+  // ~25 bisection rounds with two barriers each.  Falls through to the threshold
+  // path when a wave holds fewer than ceil(k/4) elements or the gather overflows
+  // (long runs of equal log-probs).
+  if (k >= 2) {
+    __shared__ unsigned gk[kGatherCap];
+    __shared__ float gp[kGatherCap];
+    __shared__ int gi[kGatherCap];
+    __shared__ unsigned wave_t[4], gcount;
+    unsigned tmax = 0u;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) tmax = max(tmax, key[j]);  // invalid = 0
+    // T0 = min over the 4 waves of the wave's m-th largest thread maximum,
+    // m = ceil(k / 4): every wave then holds >= m elements >= T0, >= k in all.
+    // The rank of a lane's maximum inside its wave needs no LDS (readlane).
+    const int m_need = (k + 3) >> 2;
+    const int lane = tid & 63;
+    int rank = 0;
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+      const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)tmax, u);
+      rank += (m > tmax) || (m == tmax && u < lane);
+    }
+    if (tid == 0) gcount = 0u;
+    if (rank == m_need - 1) wave_t[tid >> 6] = rank_select ? tmax : 0u;
+    __syncthreads();
+    const unsigned T0 = min(min(wave_t[0], wave_t[1]), min(wave_t[2], wave_t[3]));
+    if (T0 != 0u) {  // block-uniform
+#pragma unroll
+      for (int j = 0; j < kRowRegs; ++j)
+        if (key[j] >= T0) {  // invalid keys are 0 < T0
+          const unsigned q = atomicAdd(&gcount, 1u);
+          if (q < (unsigned)kGatherCap) { gk[q] = key[j]; gp[q] = p[j]; gi[q] = tid + 256 * j; }
+        }
+      __syncthreads();
+      const int total = (int)gcount;
+      if (total <= kGatherCap) {  // block-uniform
+        for (int c0 = tid; c0 < total; c0 += 256) {
+          const unsigned mk = gk[c0];
+          const int mi = gi[c0];
+          int r2 = 0;
+          for (int u = 0; u < total; ++u) {
+            const unsigned ok = gk[u];
+            r2 += (ok > mk) || (ok == mk && gi[u] < mi);
+          }
+          if (r2 < k) { out_v[r2] = gp[c0]; out_i[r2] = mi; }
+        }
+        return;
+      }
+    }
+    __syncthreads();
+  }
+  // greedy argmax and the threshold path work from the key range
+  unsigned kmax = 0u, kmin = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < kRowRegs; ++j)
+    if (tid + 256 * j < V) { kmax = max(kmax, key[j]); kmin = min(kmin, key[j]); }
   for (int o = 32; o > 0; o >>= 1) {
     kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o));
     kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
@@ -711,70 +769,6 @@ __global__ __launch_bounds__(256) void row_select_reg_kernel(
       out_v[0] = funkey(hi);
     }
     return;
-  }
-  // Exact top-k without a search over the key range.  A lower bound T0 that is
-  // itself close to the k-th largest element comes from the per-thread maxima
-  // (see below); the few elements >= T0 are gathered and each one's rank (key
-  // descending, index ascending among equals: the order the threshold path
-  // produces) is counted against the others -- ranks < k are the answer, already
-  // in output order.  One barrier-free wave pass and two LDS passes instead of
-  // ~25 bisection rounds with two barriers each.  Falls through to the threshold
-  // path when a wave holds fewer than ceil(k/4) elements or the gather overflows
-  // (long runs of equal log-probs).
-  {
-    __shared__ unsigned gk[kGatherCap];
-    __shared__ float gp[kGatherCap];
-    __shared__ int gi[kGatherCap];
-    __shared__ unsigned wave_t[4], gcount;
-    unsigned tmax = 0u;
-#pragma unroll
-    for (int j = 0; j < kRowRegs; ++j) tmax = max(tmax, key[j]);  // invalid = 0
-    // T0 = min over the 4 waves of the wave's m-th largest thread maximum,
-    // m = ceil(k / 4): every wave then holds >= m elements >= T0, >= k in all.
-    // The rank of a lane's maximum inside its wave needs no LDS (readlane).
-    const int m_need = (k + 3) >> 2;
-    const int lane = tid & 63;
-    int rank = 0;
-#pragma unroll
-    for (int u = 0; u < 64; ++u) {
-      const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)tmax, u);
-      rank += (m > tmax) || (m == tmax && u < lane);
-    }
-    if (tid == 0) gcount = 0u;
-    if (rank == m_need - 1) wave_t[tid >> 6] = rank_select ? tmax : 0u;
-    __syncthreads();
-    const unsigned t0s = min(min(wave_t[0], wave_t[1]), min(wave_t[2], wave_t[3]));
-    const unsigned T0 = t0s;
-    if (T0 != 0u) {
-      int c = 0;
-#pragma unroll
-      for (int j = 0; j < kRowRegs; ++j) c += key[j] >= T0;  // invalid keys are 0 < T0
-      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-      if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)c;
-      __syncthreads();
-      const int total = (int)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
-      if (total <= kGatherCap) {  // block-uniform
-#pragma unroll
-        for (int j = 0; j < kRowRegs; ++j)
-          if (key[j] >= T0) {
-            const unsigned q = atomicAdd(&gcount, 1u);
-            gk[q] = key[j]; gp[q] = p[j]; gi[q] = tid + 256 * j;
-          }
-        __syncthreads();
-        for (int c0 = tid; c0 < total; c0 += 256) {
-          const unsigned mk = gk[c0];
-          const int mi = gi[c0];
-          int r2 = 0;
-          for (int u = 0; u < total; ++u) {
-            const unsigned ok = gk[u];
-            r2 += (ok > mk) || (ok == mk && gi[u] < mi);
-          }
-          if (r2 < k) { out_v[r2] = gp[c0]; out_i[r2] = mi; }
-        }
-        return;
-      }
-      __syncthreads();
-    }
   }
   // largest T with count(key >= T) >= k   (count(key >= lo) = V >= k)
   for (int it = 0; it < 32 && lo < hi; ++it) {
