@@ -1470,6 +1470,64 @@ __global__ void gather_col_kernel(const int64_t* __restrict__ seqs, long rows,
   if (r < rows) out[r] = seqs[r * lds + t];
 }
 
+// The LM token step of the scoring loop with every operand already in split
+// format: the embedding gather writes split rows, each layer's GEMM reads
+// [input | h] as two split sources and its epilogue (EPI_LSTM) leaves h' in
+// split form for the next layer, the vocabulary GEMM and the next step -- no
+// fp32 -> split conversion launches (5 per step otherwise).  `hs` holds the
+// split hidden states, [2 slots][layers][rows][Hl]; `emb_s` (rows, El) split.
+// Same bits as lm_step.
+static bool lm_split_ok(const milan_ctx* c, int rows) {
+  const milan_dims& d = c->d;
+  if (c->precision != MILAN_PRECISION_SPLIT_F16 || !c->scratch || !c->lm_out.ws ||
+      d.lm_layers < 1 || d.lm_layers > 2 || d.lm_embedding_size % 16 ||
+      d.lm_hidden_size % 16 ||
+      (size_t)rows * d.lm_embedding_size > c->scratch_floats)
+    return false;
+  for (int l = 0; l < d.lm_layers; ++l)
+    if (!c->lm_cat[l].ws || !c->lm_cat[l].gate_interleaved) return false;
+  return true;
+}
+
+static int lm_step_split(milan_ctx* c, const int64_t* tok, int rows, LmState& st,
+                         LmState& nx, float* hs, int cur, float* logits,
+                         hipStream_t s) {
+  const milan_dims& d = c->d;
+  const int Hl = d.lm_hidden_size, El = d.lm_embedding_size, V = d.vocab_size;
+  float* emb_s = c->scratch;
+  hipLaunchKernelGGL(embed_split_kernel, dim3(nblk((long)rows * (El / 8))),
+                     dim3(256), 0, s, c->lm_embedding, tok, rows, El, emb_s, El);
+  const size_t layer_sz = (size_t)rows * Hl;
+  const float* in = emb_s;
+  int in_dim = El;
+  for (int l = 0; l < d.lm_layers; ++l) {
+    const float* h_prev = hs + ((size_t)cur * d.lm_layers + l) * layer_sz;
+    float* h_next = hs + ((size_t)(cur ^ 1) * d.lm_layers + l) * layer_sz;
+    const float* cl = st.c + (long)l * st.rows * Hl;
+    float* hn = nx.h + (long)l * nx.rows * Hl;
+    float* cn = nx.c + (long)l * nx.rows * Hl;
+    const LinearW& w = c->lm_cat[l];
+    GemmArgs g = linear_args(in, in_dim, w.ws, w.b, hn, Hl, rows, w.n, w.k,
+                             EPI_LSTM, c->zero, cl, Hl);
+    g.C2 = cn; g.Cs = h_next;
+    g.a_split = 1;
+    g.acc_scale = w.ws_inv;
+    g.Cin = in_dim;
+    g.A2 = h_prev; g.K1 = in_dim; g.H2 = 1; g.W2d = 1; g.stride2 = 1;
+    g.a2_pix_stride = Hl; g.a2_img_stride = Hl;
+    MILAN_TRY(launch_gemm(g, s));
+    in = h_next;
+    in_dim = Hl;
+  }
+  GemmArgs g = linear_args(in, Hl, c->lm_out.ws, c->lm_out.b, logits, V, rows,
+                           c->lm_out.n, c->lm_out.k, EPI_BIAS, c->zero);
+  g.a_split = 1;
+  g.acc_scale = c->lm_out.ws_inv;
+  MILAN_TRY(launch_gemm(g, s));
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // LanguageModel.forward(reduce=True), lms.py:58-101.  seq_len (device, may be
 // null) is indexed by row / len_div.
 static int lm_score_impl(milan_ctx* c, const int64_t* seqs, int rows, int L,
@@ -1487,11 +1545,21 @@ static int lm_score_impl(milan_ctx* c, const int64_t* seqs, int rows, int L,
     return 0;
   }
   int cur = 0;
+  // split hidden states live in the gate matrix, which the fused cell never writes
+  const bool split = lm_split_ok(c, rows) && (long)rows == b->lm[0].rows;
+  if (split)
+    MILAN_CHECK_HIP(hipMemsetAsync(
+        b->lm_gates, 0,
+        sizeof(float) * (size_t)rows * d.lm_hidden_size * d.lm_layers, s));
   for (int t = 0; t + 1 < L; ++t) {
     hipLaunchKernelGGL(gather_col_kernel, dim3(nblk(rows)), dim3(256), 0, s, seqs,
                        (long)rows, (long)L, t, b->tok);
-    MILAN_TRY(lm_step(c, b->tok, rows, b->lm[cur], b->lm[cur ^ 1], b->lm_emb,
-                      b->lm_gates, b->lm_logits, s));
+    if (split)
+      MILAN_TRY(lm_step_split(c, b->tok, rows, b->lm[cur], b->lm[cur ^ 1],
+                              b->lm_gates, cur, b->lm_logits, s));
+    else
+      MILAN_TRY(lm_step(c, b->tok, rows, b->lm[cur], b->lm[cur ^ 1], b->lm_emb,
+                        b->lm_gates, b->lm_logits, s));
     hipLaunchKernelGGL(lm_accumulate_kernel, dim3(rows), dim3(256), 0, s,
                        b->lm_logits, d.vocab_size, seqs, (long)L, t, seq_len,
                        len_div, d.stop_index, b->lm_alive, total);
