@@ -1552,6 +1552,16 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     if (g.tile_hint == 1) return launch_cfg<256, 128, 3, true, true>(g, s);
     if (g.tile_hint == 2) return launch_cfg<128, 128, 2, true, true>(g, s);
     if (g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);
+    {
+      // wide outputs that are not a multiple of 256 (the vocabulary GEMMs, N =
+      // 5004): the 256-column tile when it pads no more than the 128-column one
+      // would (same-box A/B: decode stage -0.5 ms; N = 3904 pads 4.9 % vs 1.6 %
+      // and is slower on it)
+      const int pad256 = (g.N + 255) / 256 * 256 - g.N;
+      const int pad128 = (g.N + 127) / 128 * 128 - g.N;
+      if (g.N > 2048 && pad256 <= pad128)
+        return launch_split16<256, 256, 4>(g, s);
+    }
     return launch_split16<256, 128, 3>(g, s);
   }
   if (g.N <= 64) {
