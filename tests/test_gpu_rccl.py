@@ -8,6 +8,7 @@ broadcast and barrier on the nccl backend, bench.py's torchrun entry.  Those run
 here with world size 1, launched the way the driver launches an N-GPU run."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -45,6 +46,12 @@ print('rccl ok')
 '''
 
 
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 def _env(port):
     env = dict(os.environ)
     env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
@@ -55,7 +62,7 @@ def _env(port):
 
 def test_sharding_collectives_on_the_nccl_backend():
     code = CHILD.format(paths=[p for p in sys.path if p])
-    done = subprocess.run([sys.executable, '-c', code], env=_env(29631),
+    done = subprocess.run([sys.executable, '-c', code], env=_env(_free_port()),
                           capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stderr[-3000:]
     assert 'rccl ok' in done.stdout
@@ -65,13 +72,14 @@ def test_bench_under_torchrun_launch_line():
     """The driver's launch line (`python -m torch.distributed.run --nnodes=1
     --nproc-per-node N ... bench.py --gpus N`) with N = 1: RANK / WORLD_SIZE /
     MASTER_* come from torchrun and one JSON line must come out."""
+    port = _free_port()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
            '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-           '--master-port', '29632', os.path.join(ROOT, 'bench.py'),
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
            '--gpus', '1', '--steps', '1', '--warmup', '0', '--chunk', '16',
            '--beam', '8', '--cpu-sample', '0', '--also-f32-steps', '0',
            '--from-host-steps', '0', '--other-configs', '0']
-    done = subprocess.run(cmd, env=_env(29632), capture_output=True, text=True,
+    done = subprocess.run(cmd, env=_env(port), capture_output=True, text=True,
                           timeout=900, cwd=ROOT)
     assert done.returncode == 0, done.stderr[-3000:]
     lines = [l for l in done.stdout.splitlines() if l.startswith('{')]
