@@ -20,6 +20,7 @@ What differs by design:
   * out of scope: training (`fit`), `bleu` / `rouge` /
     `bert_score` (need sacrebleu / rouge / bert_score), `DecoderWithCLIP`.
 """
+import os
 import weakref
 from typing import (Any, Dict, Mapping, NamedTuple, Optional, Sequence, Tuple,
                     Union)
@@ -500,14 +501,18 @@ class Decoder(nn.Module):
             # async H2D on a side stream, overlapped with the previous chunk
             from milan_amd import ingest
             dev = hip.require_device(self.device)
-            los = list(range(0, n, chunk))
+            # a short first chunk: its fetch is the only one no compute hides
+            # (results do not depend on how neurons are grouped into launches)
+            first = min(chunk, batch_size * max(1, 64 // batch_size))
+            spans = [(0, min(n, first))] if n else []
+            spans += [(lo, min(n, lo + chunk)) for lo in range(first, n, chunk)]
 
             def fetch(i):
-                images, masks = fast(los[i], min(n, los[i] + chunk))
+                images, masks = fast(*spans[i])
                 return images, (masks if mask else None)
 
-            chunks = ingest.ChunkPrefetcher(fetch, len(los), dev)
-            for images, masks in progress(chunks, len(los)):
+            chunks = ingest.ChunkPrefetcher(fetch, len(spans), dev)
+            for images, masks in progress(chunks, len(spans)):
                 with torch.no_grad():
                     output = self(images, masks, group_size=batch_size,
                                   **kwargs)
