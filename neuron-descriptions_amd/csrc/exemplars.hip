@@ -664,13 +664,28 @@ int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int
                 "sketch_add: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   if (n_ops) {
-    std::vector<SketchOp> flat;
-    flat.reserve(n_ops);
+    // the plan travels from a pinned staging buffer (a truly asynchronous copy);
+    // an event guards its reuse by the next call
+    static SketchOp* pinned = nullptr;
+    static size_t pinned_cap = 0;
+    static hipEvent_t pinned_free = nullptr;
+    static bool pinned_busy = false;
+    if (!pinned_free) MILAN_CHECK_HIP(hipEventCreateWithFlags(&pinned_free, hipEventDisableTiming));
+    if (pinned_busy) { MILAN_CHECK_HIP(hipEventSynchronize(pinned_free)); pinned_busy = false; }
+    if (pinned_cap < n_ops) {
+      if (pinned) MILAN_CHECK_HIP(hipHostFree(pinned));
+      pinned = nullptr; pinned_cap = 0;
+      const size_t cap = n_ops + n_ops / 2 + 1024;
+      MILAN_CHECK_HIP(hipHostMalloc((void**)&pinned, sizeof(SketchOp) * cap, hipHostMallocDefault));
+      pinned_cap = cap;
+    }
+    size_t o = 0;
     for (int l = 0; l < n_levels; ++l)
-      flat.insert(flat.end(), ops[l].begin(), ops[l].end());
-    // pageable source: the runtime stages it before returning
-    MILAN_CHECK_HIP(hipMemcpyAsync(d_ops, flat.data(), sizeof(SketchOp) * n_ops,
+      for (const SketchOp& op : ops[l]) pinned[o++] = op;
+    MILAN_CHECK_HIP(hipMemcpyAsync(d_ops, pinned, sizeof(SketchOp) * n_ops,
                                    hipMemcpyHostToDevice, s));
+    MILAN_CHECK_HIP(hipEventRecord(pinned_free, s));
+    pinned_busy = true;
   }
   const SketchSource src{hiddens, units, channels, hw, (long)first};
 
