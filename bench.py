@@ -168,6 +168,7 @@ def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
             'stage': name, 'what': label,
             'bound': 'hbm' if hbm_gbs / PEAK_HBM_GBS > issue else 'mfma',
             'ms_per_step': ms / n_steps,
+            'ms_per_256_neurons': ms / n_steps * 256.0 / neurons_per_step,
             'gemm_ms_per_step': gemm_ms / n_steps,
             'achieved': ach, 'peak': peak_tf, 'unit': 'TFLOP/s',
             'frac': ach / peak_tf,
@@ -188,6 +189,7 @@ def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
         out.append({
             'stage': name, 'what': label, 'bound': 'hbm',
             'ms_per_step': ms / n_steps,
+            'ms_per_256_neurons': ms / n_steps * 256.0 / neurons_per_step,
             'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
             'frac': ach / PEAK_HBM_GBS,
             'algorithmic_bytes_per_image': bytes_per_image,
@@ -226,7 +228,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=16)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--chunk', type=int, default=256,
+    ap.add_argument('--chunk', type=int, default=640,
                     help='neurons per step (per GPU)')
     ap.add_argument('--neurons-total', type=int, default=0,
                     help='whole-job neuron count, sharded over the ranks in '
@@ -299,16 +301,17 @@ def main():
         sizes = [args.chunk] * args.steps
     n_steps = len(sizes)
     my_neurons = sum(sizes)
-    # distinct resident chunks (15.4 GB of uint8 for 16); longer runs cycle
-    # through them -- every step still does the full encode + decode work.
+    # distinct resident chunks (<= 6144 neurons = 23 GB of uint8); longer runs
+    # cycle through them -- every step still does the full encode + decode work.
     # Weak mode: every rank has its own data (seed 1 + rank).  Strong mode:
     # ONE workload indexed by the global neuron number (the same on every rank,
     # so an N-rank run describes exactly the neurons of the 1-rank run).
     if strong:
-        n_pool = min(-(-args.neurons_total // 16) * 16, 16 * args.chunk)
+        n_pool = min(-(-args.neurons_total // 16) * 16,
+                     args.chunk * max(1, 6144 // args.chunk))
         seed = 1
     else:
-        n_pool = args.chunk * min(max(1, n_steps), 16)
+        n_pool = args.chunk * min(max(1, n_steps), max(1, 6144 // args.chunk))
         seed = 1 + rank
     n_data = max(1, n_pool // args.chunk)
     # uint8 exemplars resident in HBM before the timed region starts
@@ -374,7 +377,8 @@ def main():
     host_steps = n_steps if args.from_host_steps < 0 else args.from_host_steps
     if host_steps > 0:
         from milan_amd import ingest
-        nh = min(host_steps, n_steps, 4)  # <= 3.9 GB of pinned host memory
+        # <= 4.8 GB of pinned host memory
+        nh = min(host_steps, n_steps, max(1, 1280 // args.chunk))
         host = [tuple(t.cpu().pin_memory() for t in step_data[i])
                 for i in range(nh)]
         hsizes = [sizes[i % nh] for i in range(host_steps)]

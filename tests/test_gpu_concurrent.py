@@ -53,6 +53,7 @@ def test_results_identical_while_another_process_shares_the_gpu():
 
     alone = {p: run(p) for p in ('split_f16', 'f32')}
     code = CHILD.format(paths=[p for p in sys.path if p], nv=NV, seconds=20)
+    hip.release_workspaces()  # other test modules' contexts may hold 100+ GB
     child = subprocess.Popen([sys.executable, '-c', code],
                              stdout=subprocess.PIPE, text=True)
     try:

@@ -305,6 +305,7 @@ def test_config5_replicated_64k_shard_beam50(world):
 def _bench(args, nproc, port):
     env = dict(os.environ, MILAN_DIST_BACKEND='gloo',
                HSA_ENABLE_IPC_MODE_LEGACY='0')
+    hip.release_workspaces()  # the children share this GPU
     cmd = [sys.executable]
     if nproc > 1:
         cmd += ['-m', 'torch.distributed.run', '--nnodes=1',

@@ -53,6 +53,8 @@ def _free_port():
 
 
 def _env(port):
+    from milan_amd import hip
+    hip.release_workspaces()  # the child shares this GPU
     env = dict(os.environ)
     env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY='0')
