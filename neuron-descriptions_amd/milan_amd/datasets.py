@@ -138,25 +138,45 @@ class TopImagesDataset(data.Dataset):
     def units(self, indices) -> Tuple[Tuple[str, int], ...]:
         return tuple(self.unit(index) for index in indices)
 
-    def slice_uint8(self, lo: int, hi: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def slice_uint8(self, lo: int, hi: int,
+                    out: Optional[Tuple[Optional[torch.Tensor],
+                                        Optional[torch.Tensor]]] = None
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
         """Samples [lo, hi) as uint8 (n,k,3,H,W) / (n,k,1,H,W) CPU tensors
-        (same samples, in the same order, as `self[lo] .. self[hi - 1]`)."""
+        (same samples, in the same order, as `self[lo] .. self[hi - 1]`).
+
+        `out` = (images, masks) destination tensors with room for hi - lo
+        samples (e.g. pinned staging buffers; either may be None): the rows are
+        copied from the memory maps straight into them -- one pass over the
+        bytes -- and the returned tensors are views of their first n rows."""
         if not 0 <= lo <= hi <= len(self):
             raise IndexError(f'slice [{lo}, {hi}) outside dataset of '
                              f'{len(self)} samples')
-        ims, mks = [], []
+        n = hi - lo
+        runs = []
         pos = lo
         while pos < hi:
             layer, i = self._index[pos]
             run = min(hi - pos, self._valid[layer] - i)
-            ims.append(numpy.ascontiguousarray(
-                self.images_by_layer[layer][i:i + run]))
-            mks.append(numpy.ascontiguousarray(
-                self.masks_by_layer[layer][i:i + run]))
+            runs.append((layer, i, run))
             pos += run
-        images = torch.from_numpy(numpy.concatenate(ims))
-        masks = torch.from_numpy(numpy.concatenate(mks))
-        return images, masks
+
+        def gather(by_layer, dst):
+            if dst is None:
+                first = by_layer[runs[0][0] if runs else self.layers[0]]
+                dst = torch.empty((n,) + tuple(first.shape[1:]),
+                                  dtype=torch.uint8)
+            dst = dst[:n]
+            view = dst.numpy()
+            at = 0
+            for layer, i, run in runs:
+                numpy.copyto(view[at:at + run], by_layer[layer][i:i + run])
+                at += run
+            return dst
+
+        images_out, masks_out = out if out is not None else (None, None)
+        return (gather(self.images_by_layer, images_out),
+                gather(self.masks_by_layer, masks_out))
 
     def lookup(self, layer: Union[str, int], unit: int) -> TopImages:
         layer = str(layer)

@@ -504,17 +504,37 @@ class Decoder(nn.Module):
             # async H2D on a side stream, overlapped with the previous chunk
             from milan_amd import ingest
             dev = hip.require_device(self.device)
-            # a short first chunk: its fetch is the only one no compute hides
-            # (results do not depend on how neurons are grouped into launches)
-            first = min(chunk, batch_size * max(1, 64 // batch_size))
-            spans = [(0, min(n, first))] if n else []
-            spans += [(lo, min(n, lo + chunk)) for lo in range(first, n, chunk)]
+            # Chunks ramp up from 64 neurons: the first fetch is the only one no
+            # compute hides, and a chunk's compute has to cover the next
+            # chunk's fetch (results do not depend on how neurons are grouped
+            # into launches).
+            spans, lo, size = [], 0, batch_size * max(1, 64 // batch_size)
+            while lo < n:
+                size = min(size, chunk)
+                spans.append((lo, min(n, lo + size)))
+                lo += size
+                size = (size * 3 // batch_size) * batch_size
+            # datasets whose slice_uint8 takes `out=` fill the pinned staging
+            # buffers directly (one pass over the bytes)
+            import inspect
+            into = 'out' in inspect.signature(fast).parameters and n > 0
+            alloc = None
+            if into:
+                probe_im, probe_mk = fast(0, 1)
+                n_max = max(hi - lo for lo, hi in spans)
 
-            def fetch(i):
-                images, masks = fast(*spans[i])
+                def alloc():
+                    return tuple(
+                        torch.empty((n_max,) + tuple(p.shape[1:]),
+                                    dtype=torch.uint8, pin_memory=True)
+                        for p in (probe_im, probe_mk))
+
+            def fetch(i, out=None):
+                images, masks = (fast(*spans[i], out=out) if into else
+                                 fast(*spans[i]))
                 return images, (masks if mask else None)
 
-            chunks = ingest.ChunkPrefetcher(fetch, len(spans), dev)
+            chunks = ingest.ChunkPrefetcher(fetch, len(spans), dev, alloc=alloc)
             for images, masks in progress(chunks, len(spans)):
                 with torch.no_grad():
                     output = self(images, masks, group_size=batch_size,

@@ -26,9 +26,15 @@ class ChunkPrefetcher:
     rotating device buffers: consume chunk i before asking for chunk i+2.
     """
 
-    def __init__(self, fetch: Callable[[int], Chunk], n_chunks: int,
-                 device: torch.device, depth: int = 2):
+    def __init__(self, fetch: Callable[..., Chunk], n_chunks: int,
+                 device: torch.device, depth: int = 2,
+                 alloc: Optional[Callable[[], Chunk]] = None):
+        """`alloc()` (optional) returns one slot's pinned (images, masks)
+        staging buffers, sized for the largest chunk; `fetch(i, out)` is then
+        called with them and fills them in place (one pass over the bytes
+        instead of fetch + copy)."""
         self.fetch, self.n, self.device, self.depth = fetch, n_chunks, device, depth
+        self.alloc = alloc
         self.copy_stream = torch.cuda.Stream(device=device)
         self._q: 'queue.Queue' = queue.Queue()
         self._free = threading.Semaphore(depth)  # pinned slots not in flight
@@ -54,8 +60,13 @@ class ChunkPrefetcher:
         try:
             for i in range(self.n):
                 self._free.acquire()  # slot's previous H2D has completed
-                images, masks = self.fetch(i)
                 slot = i % self.depth
+                if self.alloc is not None:
+                    if self._pinned[slot] is None:
+                        self._pinned[slot] = list(self.alloc())
+                    images, masks = self.fetch(i, tuple(self._pinned[slot]))
+                else:
+                    images, masks = self.fetch(i)
                 self._q.put((i, self._pin_like(slot, images, 0),
                              self._pin_like(slot, masks, 1)))
         except BaseException as error:  # surfaced in the consumer

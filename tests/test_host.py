@@ -310,8 +310,18 @@ def test_slice_uint8_equals_getitem_when_units_file_truncates(tmp_path):
             s = ds[j]
             assert torch.equal(im[j - lo].float().mul(mul), s.images), (lo, hi, j)
             assert torch.equal(mk[j - lo].float(), s.masks)
+        if hi > lo:
+            # `out=`: rows land in caller-provided (e.g. pinned) staging buffers
+            buf_i = torch.full((9, 2, 3, 8, 8), 255, dtype=torch.uint8)
+            buf_m = torch.full((9, 2, 1, 8, 8), 255, dtype=torch.uint8)
+            im2, mk2 = ds.slice_uint8(lo, hi, out=(buf_i, buf_m))
+            assert torch.equal(im2, im) and torch.equal(mk2, mk)
+            assert im2.data_ptr() == buf_i.data_ptr()
+            im3, mk3 = ds.slice_uint8(lo, hi, out=(None, buf_m))
+            assert torch.equal(im3, im) and mk3.data_ptr() == buf_m.data_ptr()
     with pytest.raises(IndexError):
         ds.slice_uint8(0, 9)
+    assert ds.slice_uint8(3, 3)[0].shape == (0, 2, 3, 8, 8)
 
 
 # ---- sharding ------------------------------------------------------------------
