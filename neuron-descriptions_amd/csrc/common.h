@@ -89,7 +89,10 @@ struct GemmArgs {
   int aniso, stride_w, pad_w;
   int debug;          // MILAN_ABLATE timing experiments (0 in production): 1 no MFMA,
                       // 2 no DMA (igemm_kernel); 4 epilogue only, 8 main loop only (split16)
-  int tile_hint;      // 0 auto, 1 force 256x128x3-stage, 2 force 128x128x2-stage
+  int tile_hint;      // 0 auto (the kernel follows from the layer's N, K, kernel size);
+                      // experiments: 1 / 2 the round-1 256x128x3 / 128x128x2 kernels, 3 / 4 / 5
+                      // split16 256x256x4 / 256x128x3 / 128x256x3, 6 / 10 N <= 64 on / off the
+                      // 64x64-wave-tile split16 kernel, 8 the LDS-strip 3x3 kernel
   float* C2;          // EPI_LSTM: new cell state
   float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
 };
