@@ -1,0 +1,495 @@
+// Fused expand -> reduce chain of two 1x1 convolutions on the gfx950 matrix cores
+// (split-f16 mode only).
+//
+// torchvision's Bottleneck (reference call site src/milan/encoders.py:298) ends
+// with   x' = relu(bn3(conv3(t2)) + x)              (1x1, P -> 4P channels)
+// and the next block starts with
+//        t1' = relu(bn1(conv1(x')))                 (1x1, 4P -> P channels).
+// As two launches the 4P-channel tensor x' is written by the first and read back
+// by the second -- in layer3 that read is a quarter of the block's HBM traffic.
+// Here ONE launch does both: the expand output never leaves the chip on its way
+// into the reduce convolution (it is still written once, for the residual path
+// and the pyramid tap).
+//
+// Layout of the computation ("pixel per lane"): a wave owns 32 pixels for the
+// whole kernel and every MFMA is issued TRANSPOSED -- weights as the A operand
+// (rows = output channels), pixels as the B operand (columns = pixels) -- so that
+// an accumulator lane holds output channels of ONE pixel:
+//     D[n][pixel]: lane = (pixel & 31, half), register r <-> channel
+//     (r & 3) + 8 (r >> 2) + 4 half.
+// A and B fragments have the same register format (lane & 31 = row / column,
+// lane >> 5 = which 8 of the 16 k), so the expand result of a pixel, converted to
+// (hi, lo) f16 pairs, is a B fragment of the reduce product for the same lane set
+// after one trip through the wave's private LDS strip (which the epilogue needs
+// anyway to turn channel-per-register into the row-contiguous 16-byte accesses
+// HBM wants).  Per wave:
+//   t2 fragments of its 32 pixels       P / 2 registers, loaded once
+//   reduce accumulators 32 px x P       P / 2 registers, live for the whole kernel
+//   expand accumulators, one 64-channel slab at a time (32 registers)
+// P = 256 (layer3) needs ~400 registers: one wave per SIMD (4 waves, 128 pixels
+// per workgroup).  Weights stream HBM/L2 -> LDS by global_load_lds_dwordx4 in
+// 16 KB tiles (64 weight rows x 64 k) through a 4-deep ring shared by the waves;
+// a tile is 24 MFMAs per wave.  Per 64-channel slab j of the expand output:
+//   S1  expand:  acc3 = W3[slab j] . t2          (P/64 tiles)
+//   S2  epilogue: scale, + bias, + residual, ReLU, split -> HBM (x') and -> LDS
+//   S3  reduce:  acc1 += W1[:, slab j] . x'[slab j]   (P/64 tiles)
+// Accumulation order over k and the (hl, lh, hh) order of the three f16 products
+// are those of igemm_split16_kernel, and the epilogue arithmetic is the same
+// sequence of roundings, so x' and t1' are bitwise what the two separate launches
+// produce (tests/test_gpu_chain.py).
+#include "common.h"
+
+#include <cstdlib>
+
+namespace milan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+__device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// 8 fp32 -> (hi, lo) f16x8 pair, hi saturating (same roundings as gemm.hip)
+__device__ inline void chain_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh;
+    l[e] = (_Float16)(x - (float)hh);
+  }
+  *hi_out = __builtin_bit_cast(f32x4, h);
+  *lo_out = __builtin_bit_cast(f32x4, l);
+}
+
+__device__ inline void chain_join8(f32x4 hi, f32x4 lo, float* v) {
+  const f16x8 h = h8(hi), l = h8(lo);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)h[e] + (float)l[e];
+}
+
+constexpr int kSRow = 68;        // floats per row of a wave's LDS strip (64 + 4)
+constexpr int kTileFloats = 64 * 64;  // one weight tile: 64 rows x 64 k (16 KB)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+// RES_LDS: the residual slab and the bias reach the epilogue through LDS (DMA) instead
+// of registers; needs 8 KB more LDS per wave, so only the 4-wave configuration has it.
+// KD: channels of the second expand source (0 = none; then there is a residual).
+// XACC: the reduce product keeps its cross terms (hl + lh) in a second accumulator,
+// like igemm_kernel<SPLIT> does for N <= 64 layers -- same bits as that kernel.
+template <int P, int NW, bool RES_LDS, int KD, bool XACC>
+__global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
+  constexpr int N3 = 4 * P, N1 = P;
+  constexpr int K3 = P + KD;        // K of the expand product
+  constexpr int KS3 = K3 / 16;      // its k-steps (16 channels)
+  constexpr int NSLAB = N3 / 64;    // 64-channel slabs of the expand output
+  constexpr int T3 = K3 / 64;       // W3 tiles per slab (64 k each)
+  constexpr bool RES = KD == 0;     // residual epilogue (else bias + ReLU only)
+  static_assert(!(RES_LDS && !RES) && K3 % 64 == 0, "chain: configuration");
+  constexpr int T1 = N1 / 64;       // W1 tiles per slab (64 output rows each)
+  constexpr int L = T3 + T1;        // weight tiles per slab
+  constexpr int NT1 = N1 / 32;      // reduce-output MFMA tiles
+  constexpr int STAGES = 4, AHEAD = 3;
+  constexpr int PIECES = 16 / NW;   // 1 KB DMA pieces per wave per tile
+  // VMEM ops of one epilogue: 8 stores + 8 residual DMA pieces, or 8 stores + 8
+  // residual loads + 2 bias loads
+  constexpr int C_OPS = RES_LDS ? 16 : (RES ? 18 : 10);
+  static_assert(P % 64 == 0 && (NW == 4 || NW == 8), "chain: configuration");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 31, half = lane >> 5;
+  float* ring = smem;                                         // [STAGES][16 KB]
+  float* strip = smem + STAGES * kTileFloats + wave * (32 * kSRow);
+  // residual slab of the wave's 32 pixels (32 rows x 64 channels, DMA target) and
+  // the layer's expand bias
+  float* rstrip = smem + STAGES * kTileFloats + NW * (32 * kSRow) + wave * (32 * 64);
+  float* biasl = smem + STAGES * kTileFloats + NW * (32 * kSRow) + NW * (32 * 64);
+
+  const long m0 = (long)blockIdx.x * (NW * 32) + wave * 32;   // wave's first pixel
+  const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
+  const bool tail = (long)(blockIdx.x + 1) * (NW * 32) > g.M;  // workgroup-uniform
+
+  // ---- weight-tile DMA ---------------------------------------------------------
+  // tile q of the stream: slab j = q / L; qq = q % L < T3: W3 rows 64 j.., k 64 qq..;
+  // else W1 rows 64 (qq - T3).., k 64 j...  LDS row rr holds logical 16-byte chunk c
+  // at position c ^ (rr & 15) (conflict-free row-per-lane ds_read_b128).
+  const int lrow = lane >> 4;                 // row within a 4-row piece
+  const int lpos = lane & 15;
+  auto issue_tile = [&](int q) {
+    constexpr int NTILES = NSLAB * L;
+    q = q < NTILES ? q : NTILES - 1;          // dummy re-read past the end
+    const int j = q / L, qq = q - j * L;
+    const float* base;
+    long ld;
+    if (qq < T3) { base = g.W3 + (long)(64 * j) * K3 + 64 * qq; ld = K3; }
+    else { base = g.W1 + (long)(64 * (qq - T3)) * N3 + 64 * j; ld = N3; }
+    float* slot = ring + (q & (STAGES - 1)) * kTileFloats;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = wave * PIECES + i;       // piece = rows 4 pc .. 4 pc + 3
+      const int rr = 4 * pc + lrow;
+      const int c = lpos ^ (rr & 15);
+      __builtin_amdgcn_global_load_lds(
+          (const GLOBAL_AS void*)(base + (long)rr * ld + c * 4),
+          (LDS_AS void*)(slot + pc * 256), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue: t2 fragments, first residual / bias, three tiles in flight ------
+  f32x4 t2h[KS3], t2l[KS3];
+  {
+    const float* tp = g.T2 + mfrag * P + half * 8;
+#pragma unroll
+    for (int s = 0; s < P / 16; ++s) {
+      t2h[s] = *reinterpret_cast<const f32x4*>(tp + s * 16);
+      t2l[s] = *reinterpret_cast<const f32x4*>(tp + s * 16 + 4);
+    }
+    if constexpr (KD > 0) {
+      const float* ap = g.A2 + mfrag * KD + half * 8;
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) {
+        t2h[P / 16 + s] = *reinterpret_cast<const f32x4*>(ap + s * 16);
+        t2l[P / 16 + s] = *reinterpret_cast<const f32x4*>(ap + s * 16 + 4);
+      }
+    }
+  }
+  // row-major epilogue roles: 8 lanes cover the 64 channels of a row, 8 rows per pass
+  const int erow = lane >> 3, ecol = (lane & 7) * 8;
+  // Residual slab j of the wave's pixels: 8 DMA pieces (4 rows x 256 B each) into the
+  // wave's own LDS strip -- no registers, and no compiler-visible pending loads that
+  // would make it drain the weight stream.  Row r holds logical chunk c at position
+  // c ^ (r & 1) (conflict-free for the two-rows-per-group row-major reads).
+  f32x4 res[RES_LDS ? 1 : 4][2], bias3v[2];
+  auto load_res = [&](int j) {
+    if constexpr (!RES_LDS) {
+      const int n = 64 * j + ecol;
+      bias3v[0] = *reinterpret_cast<const f32x4*>(g.bias3 + n);
+      bias3v[1] = *reinterpret_cast<const f32x4*>(g.bias3 + n + 4);
+      if constexpr (!RES) return;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        long m = m0 + it * 8 + erow;
+        m = m < g.M ? m : (long)g.M - 1;
+        const float* rp = g.R + m * N3 + n;
+        res[it][0] = *reinterpret_cast<const f32x4*>(rp);
+        res[it][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 4 * i + lrow;
+      long m = m0 + r;
+      m = m < g.M ? m : (long)g.M - 1;
+      const int c = lpos ^ (r & 1);
+      __builtin_amdgcn_global_load_lds(
+          (const GLOBAL_AS void*)(g.R + m * N3 + 64 * j + c * 4),
+          (LDS_AS void*)(rstrip + i * 256), 16, 0, 0);
+    }
+  };
+  if constexpr (RES_LDS) {
+    for (int i = tid; i < N3; i += NW * 64) biasl[i] = g.bias3[i];
+  }
+  load_res(0);
+#pragma unroll
+  for (int t = 0; t < AHEAD; ++t) issue_tile(t);
+
+  f32x16 acc1[NT1], acc1x[XACC ? NT1 : 1];
+#pragma unroll
+  for (int u = 0; u < NT1; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc1[u][r] = 0.f;
+      if constexpr (XACC) acc1x[u][r] = 0.f;
+    }
+
+  // fragment of MFMA tile t (rows 32 t + px) of the weight tile in `slot`, chunk c
+  const int fsw = px & 15;
+  auto wfrag = [&](const float* slot, int t, int c) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(slot + (32 * t + px) * 64 + ((c ^ fsw) << 2));
+  };
+
+  // accumulators -> strip (channel-per-register to row-major): tile t of a 64-column
+  // slab lands in columns 32 t .. 32 t + 31 of the wave's 32 x 64 strip
+  auto to_strip = [&](const f32x16& a, int t) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      f32x4 v = {a[4 * qd], a[4 * qd + 1], a[4 * qd + 2], a[4 * qd + 3]};
+      *reinterpret_cast<f32x4*>(strip + px * kSRow + 32 * t + 8 * qd + 4 * half) = v;
+    }
+  };
+
+  // Ring protocol: at the top of iteration q tiles q and q + 1 are complete in LDS
+  // (so the first fragments of tile q + 1 can be fetched BEFORE the barrier that ends
+  // iteration q), tile q + 2 is in flight and tile q + 3 is issued into the slot tile
+  // q - 1 has just left.
+  wait_vmcnt<PIECES>();   // t2, residual, tiles 0 and 1 have landed
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // bias in LDS
+  __builtin_amdgcn_s_barrier();
+  // the t2 fragments have landed (wait above): tell the compiler, so that it does not
+  // drain the weight DMA in front of their first use inside the loop
+#pragma unroll
+  for (int s = 0; s < KS3; ++s)
+    asm volatile("" : "+v"(t2h[s]), "+v"(t2l[s]));
+
+  // weight fragments of one k-step (both 32-row MFMA tiles), double buffered: the
+  // fragments of step s + 1 are fetched while step s multiplies
+  f32x4 wh[2][2], wl[2][2];
+  auto load_w = [&](const float* slot, int s, int buf) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      wh[buf][t] = wfrag(slot, t, 4 * s + 2 * half);
+      wl[buf][t] = wfrag(slot, t, 4 * s + 2 * half + 1);
+    }
+  };
+  load_w(ring, 0, 0);
+
+  for (int j = 0; j < NSLAB; ++j) {
+    f32x16 acc3[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
+    f32x4 xh[4], xl[4];
+#pragma unroll
+    for (int qq = 0; qq < L; ++qq) {
+      const int q = j * L + qq;
+      issue_tile(q + AHEAD);
+      const float* slot = ring + (q & (STAGES - 1)) * kTileFloats;
+      const float* next_slot = ring + ((q + 1) & (STAGES - 1)) * kTileFloats;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        // (4 k-steps per tile: buffer parity is the same in every tile)
+        if (s < 3) load_w(slot, s + 1, (s + 1) & 1);
+        else load_w(next_slot, 0, 0);
+        const int b = s & 1;
+        if (qq < T3) {
+          // ---- S1: expand, k-step 4 qq + s ---------------------------------------
+          const int ks = 4 * qq + s;
+          acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+          acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][1]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+          acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
+          acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(t2l[ks]), acc3[1], 0, 0, 0);
+          acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+          acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+        } else {
+          // ---- S3: reduce, output rows 64 (qq - T3) .., k = slab j, step s ----------
+          const int u0 = 2 * (qq - T3);
+          if constexpr (XACC) {
+            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(xh[s]), acc1[u0], 0, 0, 0);
+            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(xh[s]), acc1[u0 + 1], 0, 0, 0);
+            acc1x[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][0]), h8(xh[s]), acc1x[u0], 0, 0, 0);
+            acc1x[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][1]), h8(xh[s]), acc1x[u0 + 1], 0, 0, 0);
+            acc1x[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(xl[s]), acc1x[u0], 0, 0, 0);
+            acc1x[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(xl[s]), acc1x[u0 + 1], 0, 0, 0);
+          } else {
+            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][0]), h8(xh[s]), acc1[u0], 0, 0, 0);
+            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][1]), h8(xh[s]), acc1[u0 + 1], 0, 0, 0);
+            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(xl[s]), acc1[u0], 0, 0, 0);
+            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(xl[s]), acc1[u0 + 1], 0, 0, 0);
+            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(xh[s]), acc1[u0], 0, 0, 0);
+            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(xh[s]), acc1[u0 + 1], 0, 0, 0);
+          }
+        }
+        // issue order: the four fragment reads of the NEXT k-step first, then this
+        // step's six MFMAs (one wave per SIMD: nothing else hides the LDS latency)
+        if constexpr (NW == 4) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+      }
+      if (qq == T3 - 1) {
+        // ---- S2: epilogue of slab j -------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc3[t] = acc3[t] * g.scale3;
+          to_strip(acc3[t], t);
+        }
+        const int n = 64 * j + ecol;
+        // residual slab j was issued L iterations ago: only the weight pieces issued
+        // since then may still be in flight
+        f32x4 bias0, bias1;
+        if constexpr (RES_LDS) {
+          wait_vmcnt<L * PIECES>();
+          bias0 = *reinterpret_cast<const f32x4*>(biasl + n);
+          bias1 = *reinterpret_cast<const f32x4*>(biasl + n + 4);
+        } else {
+          bias0 = bias3v[0]; bias1 = bias3v[1];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + erow;
+          const long m = m0 + row;
+          float* sp = strip + row * kSRow + ecol;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+          f32x4 rh, rl;
+          if constexpr (RES_LDS) {
+            const float* rp = rstrip + row * 64;
+            const int rsw = row & 1;
+            rh = *reinterpret_cast<const f32x4*>(rp + (((ecol >> 2)) ^ rsw) * 4);
+            rl = *reinterpret_cast<const f32x4*>(rp + (((ecol >> 2) + 1) ^ rsw) * 4);
+          } else if constexpr (RES) {
+            rh = res[it][0]; rl = res[it][1];
+          }
+          float v[8], a[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = v0[e] + bias0[e];
+            v[4 + e] = v1[e] + bias1[e];
+          }
+          if constexpr (RES) {
+            chain_join8(rh, rl, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + a[e], 0.f);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          f32x4 hi, lo;
+          chain_split8(v, &hi, &lo);
+          if (m < g.M) {
+            float* xp = g.X + m * N3 + n;
+            *reinterpret_cast<f32x4*>(xp) = hi;
+            *reinterpret_cast<f32x4*>(xp + 4) = lo;
+          }
+          *reinterpret_cast<f32x4*>(sp) = hi;      // x' in split form: a B fragment
+          *reinterpret_cast<f32x4*>(sp + 4) = lo;  // source for the reduce product
+        }
+        load_res(j + 1 < NSLAB ? j + 1 : j);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float* fp = strip + px * kSRow + (2 * s + half) * 8;
+          xh[s] = *reinterpret_cast<const f32x4*>(fp);
+          xl[s] = *reinterpret_cast<const f32x4*>(fp + 4);
+        }
+      }
+      // Tile q + 2 must have landed.  VMEM ops issued after its pieces: the pieces of
+      // tile q + 3, plus the epilogue ops of iterations q - 1 and q.
+      {
+        constexpr auto has_c = [](int i) { return ((i % L) + L) % L == T3 - 1; };
+        const int n_later = PIECES + C_OPS * ((has_c(qq - 1) ? 1 : 0) + (has_c(qq) ? 1 : 0));
+        // first slab: iterations before tile 0 do not exist
+        const int n_first = PIECES + C_OPS * ((qq - 1 >= 0 && has_c(qq - 1) ? 1 : 0) +
+                                              (has_c(qq) ? 1 : 0));
+        if (tail) {
+          // (a partly masked epilogue issues fewer stores than counted below)
+          wait_vmcnt<0>();
+        } else if (n_first != n_later && j == 0) {
+          switch (n_first) {
+            case PIECES: wait_vmcnt<PIECES>(); break;
+            default: wait_vmcnt<PIECES + C_OPS>(); break;
+          }
+        } else {
+          switch (n_later) {
+            case PIECES: wait_vmcnt<PIECES>(); break;
+            case PIECES + C_OPS: wait_vmcnt<PIECES + C_OPS>(); break;
+            default: wait_vmcnt<PIECES + 2 * C_OPS>(); break;
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  wait_vmcnt<0>();  // drain the dummy tiles before the LDS can be re-allocated
+  __builtin_amdgcn_s_barrier();
+
+  // ---- reduce epilogue: t1' = relu(acc1 * scale + bias) in split form --------------
+#pragma unroll
+  for (int cidx = 0; cidx < NT1 / 2; ++cidx) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if constexpr (XACC) acc1[2 * cidx + t] = acc1[2 * cidx + t] + acc1x[2 * cidx + t];
+      acc1[2 * cidx + t] = acc1[2 * cidx + t] * g.scale1;
+      to_strip(acc1[2 * cidx + t], t);
+    }
+    const int n = 64 * cidx + ecol;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + n);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + n + 4);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + erow;
+      const long m = m0 + row;
+      const float* sp = strip + row * kSRow + ecol;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaxf(v0[e] + b0[e], 0.f);
+        v[4 + e] = fmaxf(v1[e] + b1[e], 0.f);
+      }
+      f32x4 hi, lo;
+      chain_split8(v, &hi, &lo);
+      if (m < g.M) {
+        float* tp = g.T1 + m * N1 + n;
+        *reinterpret_cast<f32x4*>(tp) = hi;
+        *reinterpret_cast<f32x4*>(tp + 4) = lo;
+      }
+    }
+  }
+}
+
+bool chain_supported(int P, int KD) {
+  static const int off = [] { const char* e = getenv("MILAN_CHAIN"); return e && atoi(e) == 0; }();
+  if (off) return false;
+  if (KD == 0) return P == 64 || P == 128 || P == 256;
+  return P == 64 && KD == 64;
+}
+
+template <int P, int NW, bool RES_LDS, int KD, bool XACC>
+static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
+  const size_t lds = sizeof(float) * (size_t)(4 * kTileFloats + NW * 32 * kSRow +
+                                              (RES_LDS ? NW * 32 * 64 + 4 * P : 0));
+  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    attr_set = true;
+  }
+  const int rows = NW * 32;
+  const int grid = (a.M + rows - 1) / rows;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_chain(const ChainArgs& a, hipStream_t s) {
+  MILAN_REQUIRE(chain_supported(a.P, a.KD) && a.M > 0, MILAN_ERR_SHAPE,
+                "chain: unsupported planes %d (+%d)", a.P, a.KD);
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  MILAN_REQUIRE(al(a.T2) && al(a.W3) && al(a.bias3) && al(a.X) && al(a.W1) &&
+                    al(a.bias1) && al(a.T1) &&
+                    (a.KD ? (a.A2 && al(a.A2) && !a.R) : (a.R && al(a.R))),
+                MILAN_ERR_SHAPE, "chain: operands must be 16-byte aligned");
+  const double M = a.M, P = a.P, K3 = a.P + a.KD;
+  void* rec = gemm_profile_begin(
+      2.0 * M * (4 * P) * (K3 + P),
+      4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * P + 4 * P * (K3 + P)), s);
+  int r;
+  if (a.P == 256) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
+  else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);
+  else if (a.KD == 0) r = launch_chain_cfg<64, 8, false, 0, true>(a, s);
+  else r = launch_chain_cfg<64, 8, false, 64, true>(a, s);
+  gemm_profile_end(rec, s);
+  return r;
+}
+
+}  // namespace milan

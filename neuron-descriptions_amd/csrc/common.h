@@ -93,6 +93,8 @@ struct GemmArgs {
                       // experiments: 1 / 2 the round-1 256x128x3 / 128x128x2 kernels, 3 / 4 / 5
                       // split16 256x256x4 / 256x128x3 / 128x256x3, 6 / 10 N <= 64 on / off the
                       // 64x64-wave-tile split16 kernel, 8 the LDS-strip 3x3 kernel
+  int stagger;        // experiment: first-round workgroups with an odd per-XCD index start
+                      // this many microseconds late (phase-shifts neighbouring CUs)
   float* C2;          // EPI_LSTM: new cell state
   float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
 };
@@ -107,6 +109,32 @@ int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
                         long rows, int K, float scale, hipStream_t s);
 int gemm_profile_enable(int enable);
+void* gemm_profile_begin(double flops, double bytes, hipStream_t s);
+void gemm_profile_end(void* rec, hipStream_t s);
+
+// ---- fused expand -> reduce chain (chain.hip) --------------------------------
+// One launch = a bottleneck's 1x1 expand conv c3 (+ residual + ReLU) AND the next
+// bottleneck's 1x1 reduce conv c1 (+ ReLU): X = relu(T2 W3^T + b3 + R),
+// T1 = relu(X W1^T + b1); all tensors split-format, dense rows.  P = planes.
+// Optional second expand source (a bottleneck with a stride-1 downsample branch,
+// layer1.0): X = relu([T2 | A2] W3^T + b3) with W3 = [c3 | downsample] along K, no
+// residual (R == nullptr).
+struct ChainArgs {
+  const float* T2;     // [M][P]
+  const float* W3;     // [4P][P] split weights (scaled), K contiguous
+  const float* bias3;  // [4P]
+  const float* R;      // [M][4P] residual
+  float* X;            // [M][4P]
+  const float* W1;     // [P][4P] split weights (scaled)
+  const float* bias1;  // [P]
+  float* T1;           // [M][P]
+  int M, P;
+  const float* A2;     // [M][KD] or nullptr
+  int KD;              // channels of A2 (0 without)
+  float scale3, scale1;  // 1 / weight scale of W3, W1
+};
+bool chain_supported(int P, int KD);
+int launch_chain(const ChainArgs& a, hipStream_t s);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, long long* launches);
 int profile_read_stages(double* table /* [MILAN_STAGE_COUNT][6] */);

@@ -1004,7 +1004,12 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   }
   for (int li = 0; li < first_pipelined; ++li) {
     stage.emplace(MILAN_STAGE_ENC_LAYER1 + li, s);
-    for (const Bottleneck& b : c->blocks[li]) {
+    // t1_ready: pl.t1 already holds this block's c1 output -- the previous block's
+    // expand conv and this block's reduce conv ran as one launch (chain.hip)
+    bool t1_ready = false;
+    const std::vector<Bottleneck>& blocks = c->blocks[li];
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+      const Bottleneck& b = blocks[bi];
       int h1, w1, h2, w2, h3, w3;
       if (b.basic) {
         // BasicBlock (resnet18/34): relu(bn2(conv2(relu(bn1(conv1(x))))) + id)
@@ -1028,11 +1033,44 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       }
       GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
                               c->zero, &h1, &w1, split);
-      MILAN_TRY(launch_gemm(g1, s));
+      if (!t1_ready) MILAN_TRY(launch_gemm(g1, s));
+      t1_ready = false;
       GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU,
                               nullptr, c->zero, &h2, &w2, split);
       MILAN_TRY(launch_gemm(g2, s));
       const float* identity = x;
+      // Expand conv of this block + reduce conv of the next one in ONE launch: the
+      // 4P-channel block output is written once and not read back by the next c1.
+      if (split && bi + 1 < blocks.size()) {
+        const Bottleneck& nb = blocks[bi + 1];
+        const int P = b.c3.cin;
+        const bool shapes = !nb.basic && !nb.has_down && nb.c1.ws && b.c3.ws &&
+                            b.c3.kh == 1 && b.c3.kw == 1 && b.c3.stride == 1 &&
+                            b.c3.K == b.c3.Kp && b.c3.cout == 4 * P &&
+                            nb.c1.kh == 1 && nb.c1.kw == 1 && nb.c1.stride == 1 &&
+                            nb.c1.cin == 4 * P && nb.c1.cout == P &&
+                            nb.c1.K == nb.c1.Kp && b.c3.bias && nb.c1.bias;
+        const bool plain = shapes && !b.has_down && chain_supported(P, 0);
+        const bool with_ds = shapes && b.has_down && b.c3d.ws && b.down.kh == 1 &&
+                             b.down.kw == 1 && b.down.stride == 1 && h2 == h &&
+                             w2 == w && chain_supported(P, b.down.cin);
+        if (plain || with_ds) {
+          ChainArgs ca{};
+          ca.T2 = pl.t2; ca.X = y; ca.W1 = nb.c1.ws; ca.bias1 = nb.c1.bias;
+          ca.T1 = pl.t1; ca.M = n * h2 * w2; ca.P = P; ca.scale1 = nb.c1.ws_inv;
+          if (plain) {
+            ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias; ca.R = x; ca.scale3 = b.c3.ws_inv;
+          } else {
+            ca.W3 = b.c3d.ws; ca.bias3 = b.c3d.bias; ca.A2 = x; ca.KD = b.down.cin;
+            ca.scale3 = b.c3d.ws_inv;
+          }
+          MILAN_TRY(launch_chain(ca, s));
+          t1_ready = true;
+          float* tmp = x; x = y; y = tmp;
+          h = h2; w = w2;
+          continue;
+        }
+      }
       if (b.has_down && split && b.c3d.ws && b.c3d.cout > 64) {
         // c3 and the downsample as ONE GEMM over [t2 | x(strided)]
         int h3, w3;

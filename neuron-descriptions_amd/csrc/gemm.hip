@@ -661,6 +661,13 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+  if (g.stagger > 0 && blockIdx.x < (NT >= 512 ? 256 : 512) && ((blockIdx.x >> 3) & 1)) {
+    // s_memrealtime ticks at 100 MHz
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)g.stagger * 100ull)
+      __builtin_amdgcn_s_sleep(32);
+  }
+
   // loader: NT threads cover NT/4 rows x 4 chunks per pass
   const int lrow = tid >> 2;                        // 0..LROWS-1
   const int kc = (tid & 3) ^ ((tid >> 4) & 3);      // (row>>2)&3 == (tid>>4)&3
@@ -1302,6 +1309,19 @@ static ProfRec* prof_next() {
   return &g_prof.rec[g_prof.used++];
 }
 
+// hooks for launches made outside this file (chain.hip): a GEMM-class record
+void* gemm_profile_begin(double flops, double bytes, hipStream_t s) {
+  if (!g_prof.on) return nullptr;
+  ProfRec* e = prof_next();
+  if (!e) return nullptr;
+  e->stage = g_prof.stage; e->gemm = true; e->flops = flops; e->bytes = bytes;
+  (void)hipEventRecord(e->a, s);
+  return e;
+}
+void gemm_profile_end(void* rec, hipStream_t s) {
+  if (rec) (void)hipEventRecord(static_cast<ProfRec*>(rec)->b, s);
+}
+
 int gemm_profile_enable(int enable) {
   g_prof.on = enable != 0;
   g_prof.used = 0;
@@ -1472,6 +1492,10 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("MILAN_ABLATE"); dbg = e ? atoi(e) : 0; }
     g.debug = dbg;  // 1: skip MFMA phase, 2: skip DMA (timing experiments only)
+    static int stg = -1;
+    if (stg < 0) { const char* e = getenv("MILAN_STAGGER"); stg = e ? atoi(e) : 0; }
+    // the expand convs (residual / two-source epilogue-heavy launches)
+    g.stagger = (g.out_split && g.N >= 256 && g.KH == 1 && g.H > 1 && (g.aux || g.A2)) ? stg : 0;
   }
   // pick the epilogue form
   if (g.epilogue == EPI_LSTM) {
