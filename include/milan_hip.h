@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MILAN_ABI_VERSION 5
+#define MILAN_ABI_VERSION 6
 
 enum {
   MILAN_OK = 0,
@@ -220,6 +220,16 @@ int milan_graph_stats(const milan_ctx* ctx, long long* captures,
  *                             fp32-GEMM-class error at 1/3 of the f16 MFMA rate.
  * Switchable at any time between calls (both weight packings are kept). */
 enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
+
+/* Cross-layer fusions of the trunk (split-f16 mode; results are bitwise those of
+ * the unfused schedule, so this is a scheduling knob for A/B timing and tests):
+ *   MILAN_FUSE_CHAIN  a bottleneck's 1x1 expand conv (+ residual + ReLU) and the next
+ *                     bottleneck's 1x1 reduce conv run as one launch
+ *                     (csrc/chain.hip; torchvision Bottleneck.forward as called from
+ *                     src/milan/encoders.py:298).
+ * Default: all on (environment MILAN_CHAIN=0 starts a context with it off). */
+enum { MILAN_FUSE_CHAIN = 1 };
+int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);
 

@@ -451,6 +451,14 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
   return r;
 }
 
+int milan_set_fusion(milan_ctx* c, int flags) {
+  MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
+  MILAN_REQUIRE((flags & ~MILAN_FUSE_CHAIN) == 0, MILAN_ERR_ARG,
+                "unknown fusion flags %d", flags);
+  c->fusion = flags;
+  return 0;
+}
+
 int milan_set_precision(milan_ctx* c, int precision) {
   MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
   MILAN_REQUIRE(precision == MILAN_PRECISION_F32 ||

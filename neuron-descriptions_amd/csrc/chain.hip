@@ -446,8 +446,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
 }
 
 bool chain_supported(int P, int KD) {
-  static const int off = [] { const char* e = getenv("MILAN_CHAIN"); return e && atoi(e) == 0; }();
-  if (off) return false;
   if (KD == 0) return P == 64 || P == 128 || P == 256;
   return P == 64 && KD == 64;
 }

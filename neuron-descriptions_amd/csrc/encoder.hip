@@ -1041,7 +1041,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       const float* identity = x;
       // Expand conv of this block + reduce conv of the next one in ONE launch: the
       // 4P-channel block output is written once and not read back by the next c1.
-      if (split && bi + 1 < blocks.size()) {
+      if (split && (c->fusion & MILAN_FUSE_CHAIN) && bi + 1 < blocks.size()) {
         const Bottleneck& nb = blocks[bi + 1];
         const int P = b.c3.cin;
         const bool shapes = !nb.basic && !nb.has_down && nb.c1.ws && b.c3.ws &&

@@ -21,6 +21,7 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so'
 GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _RERANK
 PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
 PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16}
+FUSE_CHAIN = 1  # milan_set_fusion flag (include/milan_hip.h)
 # conv2d_nhwc test hook only: split_f16 with the LDS-strip 3x3 kernel forced
 _CONV_PRECISIONS = dict(PRECISIONS, split_f16_strip=2)
 DTYPE_U8, DTYPE_F32 = 0, 1
@@ -53,7 +54,7 @@ class Dims(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 5  # MILAN_ABI_VERSION this binding was written against
+ABI_VERSION = 6  # MILAN_ABI_VERSION this binding was written against
 
 # milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
 TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET, TRUNK_NONE = 0, 1, 2, 3
@@ -100,6 +101,7 @@ SIGNATURES = {
         _P, ctypes.POINTER(ctypes.c_longlong),
         ctypes.POINTER(ctypes.c_longlong)
     ]),
+    'milan_set_fusion': (_I, [_P, _I]),
     'milan_set_precision': (_I, [_P, _I]),
     'milan_get_precision': (_I, [_P]),
     'milan_profile_enable': (_I, [_I]),
@@ -245,6 +247,8 @@ class Context:
             del keep
         self._ws: Optional[torch.Tensor] = None
         _LIVE_CONTEXTS.add(self)
+        if os.environ.get('MILAN_CHAIN') == '0':  # A/B timing (tools/ab_env.sh)
+            self.set_fusion(chain=False)
         default = os.environ.get('MILAN_PRECISION')
         if default:
             self.set_precision(default)
@@ -284,6 +288,10 @@ class Context:
                 raise ValueError(f'unknown precision: {precision}')
             precision = PRECISIONS[precision]
         _check(self.lib.milan_set_precision(self._h, int(precision)))
+
+    def set_fusion(self, chain: bool = True) -> None:
+        """Cross-layer fusions of the trunk (bitwise-neutral scheduling knob)."""
+        _check(self.lib.milan_set_fusion(self._h, FUSE_CHAIN if chain else 0))
 
     @property
     def precision(self) -> str:
