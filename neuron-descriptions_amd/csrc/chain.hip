@@ -89,8 +89,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 // KD: channels of the second expand source (0 = none; then there is a residual).
 // XACC: the reduce product keeps its cross terms (hl + lh) in a second accumulator,
 // like igemm_kernel<SPLIT> does for N <= 64 layers -- same bits as that kernel.
-template <int P, int NW, bool RES_LDS, int KD, bool XACC>
+template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
+  long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0;
+  auto stamp = [&](int k) {
+    if constexpr (PROF) {
+      const long long t = __builtin_readcyclecounter();
+      tprof[k] += t - tlast;
+      tlast = t;
+    }
+  };
+  if constexpr (PROF) tlast = __builtin_readcyclecounter();
   constexpr int N3 = 4 * P, N1 = P;
   constexpr int K3 = P + KD;        // K of the expand product
   constexpr int KS3 = K3 / 16;      // its k-steps (16 channels)
@@ -101,7 +111,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   constexpr int T1 = N1 / 64;       // W1 tiles per slab (64 output rows each)
   constexpr int L = T3 + T1;        // weight tiles per slab
   constexpr int NT1 = N1 / 32;      // reduce-output MFMA tiles
-  constexpr int STAGES = 4, AHEAD = 3;
+  // Ring depth.  Every workgroup of an XCD walks the weight stream in step, so a tile
+  // is an L2 miss for the first one and ~2 us away; what hides that is BYTES IN
+  // FLIGHT.  The 4-wave configuration spends its LDS on a 7-slot ring (5 tiles = 80 KB
+  // in flight); the residual slab then lands in the wave's strip itself (it is idle
+  // between two epilogues).
+  constexpr int STAGES = RES_LDS ? 7 : 4, AHEAD = STAGES - 1;
+  constexpr int INFL = AHEAD - 2;   // tiles still in flight behind a complete tile q + 2
   constexpr int PIECES = 16 / NW;   // 1 KB DMA pieces per wave per tile
   // VMEM ops of one epilogue: 8 stores + 8 residual DMA pieces, or 8 stores + 8
   // residual loads + 2 bias loads
@@ -115,10 +131,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   const int px = lane & 31, half = lane >> 5;
   float* ring = smem;                                         // [STAGES][16 KB]
   float* strip = smem + STAGES * kTileFloats + wave * (32 * kSRow);
-  // residual slab of the wave's 32 pixels (32 rows x 64 channels, DMA target) and
-  // the layer's expand bias
-  float* rstrip = smem + STAGES * kTileFloats + NW * (32 * kSRow) + wave * (32 * 64);
-  float* biasl = smem + STAGES * kTileFloats + NW * (32 * kSRow) + NW * (32 * 64);
+  // residual slab of the wave's 32 pixels (32 rows x 64 channels, DMA target: read
+  // into registers at the start of the epilogue, before the accumulators overwrite
+  // it) and the layer's expand bias
+  float* rstrip = strip;  // 32 rows x 64 floats, unpadded, at the start of the strip
+  float* biasl = smem + STAGES * kTileFloats + NW * (32 * kSRow);
 
   const long m0 = (long)blockIdx.x * (NW * 32) + wave * 32;   // wave's first pixel
   const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
     long ld;
     if (qq < T3) { base = g.W3 + (long)(64 * j) * K3 + 64 * qq; ld = K3; }
     else { base = g.W1 + (long)(64 * (qq - T3)) * N3 + 64 * j; ld = N3; }
-    float* slot = ring + (q & (STAGES - 1)) * kTileFloats;
+    float* slot = ring + (q % STAGES) * kTileFloats;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int pc = wave * PIECES + i;       // piece = rows 4 pc .. 4 pc + 3
@@ -238,9 +255,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   // (so the first fragments of tile q + 1 can be fetched BEFORE the barrier that ends
   // iteration q), tile q + 2 is in flight and tile q + 3 is issued into the slot tile
   // q - 1 has just left.
-  wait_vmcnt<PIECES>();   // t2, residual, tiles 0 and 1 have landed
+  wait_vmcnt<INFL * PIECES>();   // t2, residual, tiles 0 and 1 have landed
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // bias in LDS
   __builtin_amdgcn_s_barrier();
+  stamp(0);
   // the t2 fragments have landed (wait above): tell the compiler, so that it does not
   // drain the weight DMA in front of their first use inside the loop
 #pragma unroll
@@ -248,14 +266,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
     asm volatile("" : "+v"(t2h[s]), "+v"(t2l[s]));
 
   // weight fragments of one k-step (both 32-row MFMA tiles), double buffered: the
-  // fragments of step s + 1 are fetched while step s multiplies
+  // fragments of step s + 1 are fetched while step s multiplies.  With one wave per
+  // SIMD (NW == 4) nothing else hides the LDS latency, and the compiler's own
+  // lgkmcnt(0) in front of a step would also drain the reads just issued for the
+  // next one -- so that configuration issues the reads and the counted wait itself
+  // (the wait names the fragment registers, which keeps the MFMAs behind it).
   f32x4 wh[2][2], wl[2][2];
   auto load_w = [&](const float* slot, int s, int buf) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      wh[buf][t] = wfrag(slot, t, 4 * s + 2 * half);
-      wl[buf][t] = wfrag(slot, t, 4 * s + 2 * half + 1);
+      if constexpr (NW == 4) {
+        const float* ph = slot + (32 * t + px) * 64 + (((4 * s + 2 * half) ^ fsw) << 2);
+        const float* pl = slot + (32 * t + px) * 64 + (((4 * s + 2 * half + 1) ^ fsw) << 2);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wh[buf][t]) : "v"((LDS_AS const float*)ph) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wl[buf][t]) : "v"((LDS_AS const float*)pl) : "memory");
+      } else {
+        wh[buf][t] = wfrag(slot, t, 4 * s + 2 * half);
+        wl[buf][t] = wfrag(slot, t, 4 * s + 2 * half + 1);
+      }
     }
+  };
+  // fragments of buffer `buf` have landed; the four reads issued after them may fly
+  auto wait_w = [&](int buf) {
+    if constexpr (NW == 4)
+      asm volatile("s_waitcnt lgkmcnt(4)"
+                   : "+v"(wh[buf][0]), "+v"(wh[buf][1]), "+v"(wl[buf][0]), "+v"(wl[buf][1])
+                   :: "memory");
   };
   load_w(ring, 0, 0);
 
@@ -270,14 +306,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
     for (int qq = 0; qq < L; ++qq) {
       const int q = j * L + qq;
       issue_tile(q + AHEAD);
-      const float* slot = ring + (q & (STAGES - 1)) * kTileFloats;
-      const float* next_slot = ring + ((q + 1) & (STAGES - 1)) * kTileFloats;
+      stamp(1);
+      const float* slot = ring + (q % STAGES) * kTileFloats;
+      const float* next_slot = ring + ((q + 1) % STAGES) * kTileFloats;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         // (4 k-steps per tile: buffer parity is the same in every tile)
         if (s < 3) load_w(slot, s + 1, (s + 1) & 1);
         else load_w(next_slot, 0, 0);
         const int b = s & 1;
+        wait_w(b);
         if (qq < T3) {
           // ---- S1: expand, k-step 4 qq + s ---------------------------------------
           const int ks = 4 * qq + s;
@@ -306,30 +344,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
             acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(xh[s]), acc1[u0 + 1], 0, 0, 0);
           }
         }
-        // issue order: the four fragment reads of the NEXT k-step first, then this
-        // step's six MFMAs (one wave per SIMD: nothing else hides the LDS latency)
-        if constexpr (NW == 4) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        }
+
       }
+      stamp(2);
       if (qq == T3 - 1) {
         // ---- S2: epilogue of slab j -------------------------------------------------
+        const int n = 64 * j + ecol;
+        f32x4 bias0, bias1, rh4[4], rl4[4];
+        if constexpr (RES_LDS) {
+          // residual slab j was issued L iterations ago: only the weight pieces issued
+          // since then may still be in flight
+          wait_vmcnt<(L * PIECES < 63 ? L * PIECES : 63)>();
+          bias0 = *reinterpret_cast<const f32x4*>(biasl + n);
+          bias1 = *reinterpret_cast<const f32x4*>(biasl + n + 4);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + erow;
+            const float* rp = rstrip + row * 64;
+            const int rsw = row & 1;
+            rh4[it] = *reinterpret_cast<const f32x4*>(rp + (((ecol >> 2)) ^ rsw) * 4);
+            rl4[it] = *reinterpret_cast<const f32x4*>(rp + (((ecol >> 2) + 1) ^ rsw) * 4);
+          }
+        } else {
+          bias0 = bias3v[0]; bias1 = bias3v[1];
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           acc3[t] = acc3[t] * g.scale3;
           to_strip(acc3[t], t);
-        }
-        const int n = 64 * j + ecol;
-        // residual slab j was issued L iterations ago: only the weight pieces issued
-        // since then may still be in flight
-        f32x4 bias0, bias1;
-        if constexpr (RES_LDS) {
-          wait_vmcnt<L * PIECES>();
-          bias0 = *reinterpret_cast<const f32x4*>(biasl + n);
-          bias1 = *reinterpret_cast<const f32x4*>(biasl + n + 4);
-        } else {
-          bias0 = bias3v[0]; bias1 = bias3v[1];
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -340,10 +382,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
           f32x4 rh, rl;
           if constexpr (RES_LDS) {
-            const float* rp = rstrip + row * 64;
-            const int rsw = row & 1;
-            rh = *reinterpret_cast<const f32x4*>(rp + (((ecol >> 2)) ^ rsw) * 4);
-            rl = *reinterpret_cast<const f32x4*>(rp + (((ecol >> 2) + 1) ^ rsw) * 4);
+            rh = rh4[it]; rl = rl4[it];
           } else if constexpr (RES) {
             rh = res[it][0]; rl = res[it][1];
           }
@@ -371,39 +410,51 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
           *reinterpret_cast<f32x4*>(sp) = hi;      // x' in split form: a B fragment
           *reinterpret_cast<f32x4*>(sp + 4) = lo;  // source for the reduce product
         }
-        load_res(j + 1 < NSLAB ? j + 1 : j);
+        if constexpr (!RES_LDS) load_res(j + 1 < NSLAB ? j + 1 : j);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const float* fp = strip + px * kSRow + (2 * s + half) * 8;
           xh[s] = *reinterpret_cast<const f32x4*>(fp);
           xl[s] = *reinterpret_cast<const f32x4*>(fp + 4);
         }
+        if constexpr (RES_LDS) {
+          // the next residual slab lands in the strip: its last readers (the x'
+          // fragment reads above) must have returned first
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]),
+                         "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3])
+                       :: "memory");
+          load_res(j + 1 < NSLAB ? j + 1 : j);
+        }
       }
+      stamp(3);
       // Tile q + 2 must have landed.  VMEM ops issued after its pieces: the pieces of
-      // tile q + 3, plus the epilogue ops of iterations q - 1 and q.
+      // tiles q + 3 .. q + AHEAD, plus the epilogue ops of iterations q - INFL .. q.
       {
         constexpr auto has_c = [](int i) { return ((i % L) + L) % L == T3 - 1; };
-        const int n_later = PIECES + C_OPS * ((has_c(qq - 1) ? 1 : 0) + (has_c(qq) ? 1 : 0));
-        // first slab: iterations before tile 0 do not exist
-        const int n_first = PIECES + C_OPS * ((qq - 1 >= 0 && has_c(qq - 1) ? 1 : 0) +
-                                              (has_c(qq) ? 1 : 0));
+        int c_later = 0, c_first = 0;
+#pragma unroll
+        for (int d = 0; d <= INFL; ++d) {
+          c_later += has_c(qq - d) ? 1 : 0;
+          c_first += (qq - d >= 0 && has_c(qq - d)) ? 1 : 0;  // first slab
+        }
+        const int cnt = (j == 0) ? c_first : c_later;
+        constexpr int B = INFL * PIECES;
         if (tail) {
           // (a partly masked epilogue issues fewer stores than counted below)
           wait_vmcnt<0>();
-        } else if (n_first != n_later && j == 0) {
-          switch (n_first) {
-            case PIECES: wait_vmcnt<PIECES>(); break;
-            default: wait_vmcnt<PIECES + C_OPS>(); break;
-          }
         } else {
-          switch (n_later) {
-            case PIECES: wait_vmcnt<PIECES>(); break;
-            case PIECES + C_OPS: wait_vmcnt<PIECES + C_OPS>(); break;
-            default: wait_vmcnt<PIECES + 2 * C_OPS>(); break;
+          switch (cnt) {
+            case 0: wait_vmcnt<B>(); break;
+            case 1: wait_vmcnt<(B + C_OPS < 63 ? B + C_OPS : 63)>(); break;
+            case 2: wait_vmcnt<(B + 2 * C_OPS < 63 ? B + 2 * C_OPS : 63)>(); break;
+            default: wait_vmcnt<(B + 3 * C_OPS < 63 ? B + 3 * C_OPS : 63)>(); break;
           }
         }
       }
+      stamp(4);
       __builtin_amdgcn_s_barrier();
+      stamp(5);
     }
   }
   wait_vmcnt<0>();  // drain the dummy tiles before the LDS can be re-allocated
@@ -443,6 +494,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
       }
     }
   }
+  if constexpr (PROF) {
+    stamp(6);
+    if (tid == 0 && g.prof)
+      for (int k = 0; k < 8; ++k) g.prof[(long)blockIdx.x * 8 + k] = tprof[k];
+  }
 }
 
 bool chain_supported(int P, int KD) {
@@ -450,11 +506,11 @@ bool chain_supported(int P, int KD) {
   return P == 64 && KD == 64;
 }
 
-template <int P, int NW, bool RES_LDS, int KD, bool XACC>
+template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false>
 static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
-  const size_t lds = sizeof(float) * (size_t)(4 * kTileFloats + NW * 32 * kSRow +
-                                              (RES_LDS ? NW * 32 * 64 + 4 * P : 0));
-  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC>;
+  const size_t lds = sizeof(float) * (size_t)((RES_LDS ? 7 : 4) * kTileFloats +
+                                              NW * 32 * kSRow + (RES_LDS ? 4 * P : 0));
+  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF>;
   static bool attr_set = false;
   if (!attr_set) {
     MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -482,7 +538,8 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
       2.0 * M * (4 * P) * (K3 + P),
       4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * P + 4 * P * (K3 + P)), s);
   int r;
-  if (a.P == 256) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
+  if (a.P == 256 && a.prof) r = launch_chain_cfg<256, 4, true, 0, false, true>(a, s);
+  else if (a.P == 256) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
   else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);
   else if (a.KD == 0) r = launch_chain_cfg<64, 8, false, 0, true>(a, s);
   else r = launch_chain_cfg<64, 8, false, 64, true>(a, s);

@@ -132,6 +132,7 @@ struct ChainArgs {
   const float* A2;     // [M][KD] or nullptr
   int KD;              // channels of A2 (0 without)
   float scale3, scale1;  // 1 / weight scale of W3, W1
+  long long* prof;       // timing experiments: per-workgroup phase cycles (8 per WG)
 };
 bool chain_supported(int P, int KD);
 int launch_chain(const ChainArgs& a, hipStream_t s);
