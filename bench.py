@@ -246,11 +246,6 @@ def main():
                     help='neurons for the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-profile', action='store_true',
                     help='do not bracket GEMM launches / stages with HIP events')
-    ap.add_argument('--pipeline', type=int, default=0,
-                    help='1: run the encoder of step i+1 on a second HIP stream '
-                    'while step i decodes (measured +2%% with --no-profile, 2x '
-                    'slower with per-launch event profiling on); 0: strictly '
-                    'serial steps (default)')
     ap.add_argument('--from-host-steps', type=int, default=-1,
                     help='steps of the PCIe-inclusive leg (pinned host uint8 -> '
                     'double-buffered H2D -> describe -> D2H of tokens + scores); '
@@ -346,14 +341,7 @@ def main():
     if not args.no_profile:
         hip.profile_enable(True)
     t0 = time.perf_counter()
-    if args.pipeline and strategy != hip.GREEDY:
-        # encoder of step i+1 overlaps the decode loop of step i (two streams)
-        chunks = (chunk_of(i, sizes[i]) for i in range(n_steps))
-        outs = list(ctx.describe_pipelined(chunks, strategy, args.length, beam,
-                                           False, args.temperature,
-                                           group_size=16))
-    else:
-        outs = [step(i, sizes[i]) for i in range(n_steps)]
+    outs = [step(i, sizes[i]) for i in range(n_steps)]
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = time.perf_counter() - t0
@@ -403,9 +391,8 @@ def main():
         e_host = sharding.max_over_ranks(time.perf_counter() - t2, device)
         pcie = (sum(hsizes), e_host)
         # same data, same kernels: the host leg must reproduce the resident run
-        if not args.pipeline:
-            for i in range(min(host_steps, nh)):
-                assert torch.equal(tok_host[i], outs[i]['tokens'].cpu()), i
+        for i in range(min(host_steps, nh)):
+            assert torch.equal(tok_host[i], outs[i]['tokens'].cpu()), i
         del host
 
     # secondary measurement in the exact-fp32 mode (same workload, fewer steps)

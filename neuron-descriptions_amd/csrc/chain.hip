@@ -501,6 +501,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   }
 }
 
+// (Round 3 also built a producer / consumer form for P = 256 -- expand waves holding t2
+// and issuing all DMA, reduce waves running the epilogue and S3 one slab behind, one of
+// each per SIMD.  Bitwise correct, 8.6 ms per layer3 block pair against 7.5 ms for the
+// 4-wave form above and 8.0 ms for the two separate launches: with a barrier per
+// weight tile the reduce wave's epilogue (63 k of 212 k cycles per workgroup) still
+// runs while its partner waits, and both waves' MFMAs share one pipe.  Removed from the
+// library; numbers in DESIGN.md section 5.)
+
 bool chain_supported(int P, int KD) {
   if (KD == 0) return P == 64 || P == 128 || P == 256;
   return P == 64 && KD == 64;

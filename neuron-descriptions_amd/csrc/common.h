@@ -187,6 +187,7 @@ __host__ __device__ inline int lstm_interleaved_row(int gate, int u) {
   return (u >> 4) * 64 + gate * 16 + (u & 15);
 }
 
+
 // ---- packed weights ----------------------------------------------------------
 struct ConvW {
   float* w = nullptr;     // [Cout][Kp]

@@ -610,106 +610,6 @@ class Context:
         return out
 
 
-    # -- two-stream pipeline ---------------------------------------------------
-    def describe_pipelined(self,
-                           chunks,
-                           strategy: int,
-                           length: int,
-                           beam: int,
-                           mi: bool,
-                           temperature: float,
-                           group_size: int = 0):
-        """Yield one output dict per (images, masks) chunk, with the encoder of
-        chunk i+1 running on its own HIP stream while chunk i decodes.
-
-        The trunk's convolutions are large MFMA-bound grids; the decode loop is
-        ~450 small, latency-bound launches.  On
-        separate streams (milan_encode / milan_decode take the stream and the
-        workspace from the caller) the decode kernels could fill the gaps of
-        the encoder grid.  MEASURED (round 1): 1021 vs 1005 neurons/s serial
-        (+2 %; two fully independent contexts on two streams: +3.5 %) -- the
-        convolution grids already fill every CU, so only the decode loop's own
-        latency gaps are recovered; with per-launch event profiling on, the
-        pipelined order is 2x SLOWER.  Kept for experiments
-        (bench.py --pipeline 1), not used by predict().
-        """
-        dev = self.device
-        cur = torch.cuda.current_stream(dev)
-        enc_s = torch.cuda.Stream(device=dev)
-        dec_s = torch.cuda.Stream(device=dev)  # (high-priority decode: -11 %)
-        feats = [None, None]
-        feats_free = [None, None]
-        ws = {}
-
-        def workspace(tag, need):
-            t = ws.get(tag)
-            if t is None or t.numel() < need:
-                ws[tag] = t = torch.empty(need, dtype=torch.uint8, device=dev)
-            return t
-
-        pending = None
-        for i, (images, masks) in enumerate(chunks):
-            n, k, ch, h, w = images.shape
-            idt = DTYPE_U8 if images.dtype == torch.uint8 else DTYPE_F32
-            images = _dev(images, dev, None if idt == DTYPE_U8 else torch.float32)
-            mdt = DTYPE_U8
-            if masks is not None:
-                mdt = DTYPE_U8 if masks.dtype == torch.uint8 else DTYPE_F32
-                masks = _dev(masks, dev,
-                             None if mdt == DTYPE_U8 else torch.float32)
-            slot = i & 1
-            fsz = self.dims.feature_size
-            if feats[slot] is None or feats[slot].shape[:2] != (n, k):
-                feats[slot] = torch.empty(n, k, fsz, device=dev)
-            ws_e = workspace('enc', int(self.lib.milan_workspace_bytes(
-                self._h, n, k, max(h, w), 1, 1)))
-            ws_d = workspace('dec', int(self.lib.milan_workspace_bytes(
-                self._h, n, k, 0, beam, length)))
-            enc_s.wait_stream(cur)  # inputs were produced on the caller's stream
-            if feats_free[slot] is not None:
-                enc_s.wait_event(feats_free[slot])
-            with torch.cuda.device(dev), torch.cuda.stream(enc_s):
-                _check(
-                    self.lib.milan_encode(self._h, images.data_ptr(), idt,
-                                          _ptr(masks), mdt, n * k, h, w,
-                                          feats[slot].data_ptr(),
-                                          ws_e.data_ptr(), ws_e.numel(),
-                                          enc_s.cuda_stream))
-                encoded = torch.cuda.Event()
-                encoded.record(enc_s)
-            images.record_stream(enc_s)
-            if masks is not None:
-                masks.record_stream(enc_s)
-            with torch.cuda.device(dev), torch.cuda.stream(dec_s):
-                dec_s.wait_event(encoded)
-                out = self._alloc_outputs(n, k, strategy, length, beam, False)
-                groups = (n + group_size - 1) // group_size if group_size > 0 \
-                    else 1
-                out['out_len'] = torch.full((groups,), length,
-                                            dtype=torch.int32, device=dev)
-                _check(
-                    self.lib.milan_decode(
-                        self._h, feats[slot].data_ptr(), n, k, strategy, length,
-                        beam, int(bool(mi)), float(temperature), group_size,
-                        out['tokens'].data_ptr(), out['scores'].data_ptr(),
-                        None, None, _ptr(out['beam_tokens']),
-                        _ptr(out['beam_scores']), out['out_len'].data_ptr(),
-                        ws_d.data_ptr(), ws_d.numel(), dec_s.cuda_stream))
-                done = torch.cuda.Event()
-                done.record(dec_s)
-            feats_free[slot] = done
-            for t in out.values():
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(cur)
-            if pending is not None:
-                cur.wait_event(pending[1])
-                yield pending[0]
-            pending = (out, done)
-        if pending is not None:
-            cur.wait_event(pending[1])
-            yield pending[0]
-
-
 def profile_enable(enable: bool) -> None:
     _check(load_library().milan_profile_enable(int(enable)))
 
