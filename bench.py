@@ -91,9 +91,17 @@ def pooled_bytes_per_image(masks: torch.Tensor, width: int = 64) -> float:
     return total / m.shape[0]
 
 
-def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None):
-    """Time the oracle (kind 'port') on the host cores on a bounded sample;
-    with `gpu_describe`, also check the HIP path against it on that sample."""
+def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None,
+                 gpu_encode_modes=None, gpu_config1=None):
+    """Time the oracle (kind 'port') on the host cores on a bounded sample; with
+    `gpu_describe`, also check the HIP path against it on that sample.
+
+    `gpu_encode_modes(images, masks) -> {mode: features}`: the precision evidence --
+    the first 8 neurons of the sample are also encoded by the oracle in float64, and
+    every arithmetic (this run's mode, the exact-fp32 MFMA mode, the fp32 CPU oracle)
+    is priced against that.  `gpu_config1`: SURVEY 8(d)'s own baseline definition
+    (config 1: 256 neurons, greedy, mi=False, batch 16) on a bounded sample of it.
+    """
     from oracle import milan_oracle as O
     # torch's CPU conv collapses when oversubscribed on many-core hosts (256
     # threads: 88 s/neuron measured in round 1); cap the pool and say so.
@@ -118,9 +126,18 @@ def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None):
         got = gpu_describe(images, masks)
         tp = want['tokens'].shape[1]
         same = (got['tokens'][:, :tp].cpu() == want['tokens']).all(dim=1)
+        # a differing description is a NEAR-TIE when the oracle's own top-2 gap of the
+        # rerank score is below 1e-3 (scores are sums of <= 15 log-probs around -50)
+        margin = want.get('rerank_margin')
+        near = int(((~same) & (margin < 1e-3)).sum()) if margin is not None else None
         parity = {
             'neurons': sample,
             'identical_descriptions': int(same.sum()),
+            'different_at_oracle_near_tie': near,
+            'different_otherwise': (int((~same).sum()) - near
+                                    if near is not None else None),
+            'smallest_oracle_top2_margin': (float(margin.min())
+                                            if margin is not None else None),
             'max_abs_feature_diff': float(
                 (got['features'].cpu() - feats).abs().max()),
             'feature_scale': float(feats.abs().max()),
@@ -128,8 +145,62 @@ def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None):
                 (got['scores'].cpu() - want['scores'])[same].abs().max())
             if same.any() else None,
         }
+    dtype_error = None
+    if gpu_encode_modes is not None:
+        n64 = min(8, sample)
+        sd64 = {k: (v.double() if v.is_floating_point() else v)
+                for k, v in sd.items()}
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            ref64 = O.encode(O.byte_to_float(images[:n64]).double(),
+                             masks[:n64].double(), sd64, chunk=15)
+            t64 = time.perf_counter() - t1
+        scale = float(ref64.abs().max())
+
+        def err(x):
+            d = (x.double().cpu() - ref64).abs()
+            return {'max_abs': float(d.max()), 'max_rel_to_scale': float(d.max()) / scale,
+                    'rms_rel_to_scale': float(d.pow(2).mean().sqrt()) / scale}
+
+        dtype_error = {
+            'reference': (f'oracle encoder in float64 on the first {n64} neurons '
+                          f'({n64 * 15} feature vectors of 3904, {t64:.1f} s)'),
+            'feature_scale': scale,
+            'oracle_fp32': err(feats[:n64]),
+        }
+        for mode, f in gpu_encode_modes(images[:n64], masks[:n64]).items():
+            dtype_error[mode] = err(f)
+    config1 = None
+    if gpu_config1 is not None:
+        # config 1 = 256 neurons, greedy, mi=False, reference batch 16,
+        # all host cores (capped, see above), 1 warm-up batch + timed batches; the
+        # full 256-neuron pass would take ~2 minutes, so 2 batches are timed
+        im1, mk1 = synthetic.exemplars(48, k=15, size=224, seed=3)
+        with torch.no_grad():
+            def batch(lo):
+                f = O.encode(O.byte_to_float(im1[lo:lo + 16]), mk1[lo:lo + 16].float(),
+                             sd, chunk=15)
+                return O.forward(f, sd, nv, 'greedy', length, 1, temperature, mi=False)
+            batch(0)
+            t2 = time.perf_counter()
+            outs1 = [batch(16), batch(32)]
+            t_c1 = time.perf_counter() - t2
+        got1 = gpu_config1(im1[16:48], mk1[16:48])
+        want1 = torch.cat([o['tokens'] for o in outs1])
+        config1 = {
+            'value': 32 / t_c1, 'unit': 'neuron-descriptions/sec', 'cores': cores,
+            'kind': 'port',
+            'sample': ('SURVEY 8(d) config 1 (alexnet conv5 width: 256 neurons, greedy, '
+                       'mi=False, batch 16): 1 warm-up batch + 2 timed batches of 16 '
+                       'of the 16 in a full pass'),
+            'identical_greedy_descriptions_hip_vs_oracle': int(
+                (got1['tokens'].cpu() == want1).all(dim=1).sum()),
+            'neurons_checked': 32,
+        }
     return {
         'parity_vs_oracle': parity,
+        'dtype_error': dtype_error,
+        'config1': config1,
         'value': sample / t_all,
         'unit': 'neuron-descriptions/sec',
         'cores': torch.get_num_threads(),
@@ -139,6 +210,66 @@ def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None):
                    f'{torch.get_num_threads()} threads of {os.cpu_count()} '
                    f'cpus; encoder {t_enc:.1f}s of {t_all:.1f}s'),
     }
+
+
+def measure_traffic_live(args):
+    """HBM bytes per launch of the dominant GEMM kernel, measured NOW: two child runs of
+    this script (one step, same chunk, same precision) under `rocprofv3 --kernel-trace
+    --pmc FETCH_SIZE` and `... WRITE_SIZE` (PMC needs its own passes; FETCH_SIZE and
+    WRITE_SIZE do not fit one pass on gfx950), read back from rocprofv3's database.
+    Counter unit KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.
+    Returns (bytes_per_launch, note) or (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which('rocprofv3')
+    if rocprof is None:
+        return None, 'rocprofv3 is not on PATH'
+    totals = {}
+    with tempfile.TemporaryDirectory(dir='/tmp') as tmp:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'p',
+                   '--', sys.executable, str(REPO / 'bench.py'), '--steps', '1',
+                   '--warmup', '0', '--chunk', str(args.chunk), '--precision',
+                   args.precision, '--also-f32-steps', '0', '--cpu-sample', '0',
+                   '--no-profile', '--from-host-steps', '0', '--other-configs', '0',
+                   '--live-traffic', '0']
+            env = dict(os.environ, TMPDIR='/tmp')
+            try:
+                r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True,
+                                   text=True, timeout=600)
+            except subprocess.TimeoutExpired:
+                return None, f'rocprofv3 --pmc {counter} pass timed out'
+            dbs = glob.glob(os.path.join(out, '**', '*.db'), recursive=True)
+            if r.returncode != 0 or not dbs:
+                lines = [ln for ln in r.stderr.splitlines()
+                         if 'rocprofv3]' not in ln and 'simple_timer' not in ln and
+                         'amdgpu.ids' not in ln]
+                return None, (f'rocprofv3 --pmc {counter} pass failed '
+                              f'(rc {r.returncode}): ' + ' | '.join(lines[-4:])[-400:])
+            db = sqlite3.connect(dbs[0])
+            q = ('select kernel_name, count(*), sum(value) from counters_collection '
+                 'where counter_name = ? group by kernel_name')
+            for name, launches, total in db.execute(q, (counter,)):
+                if 'igemm' in name or 'chain_kernel' in name:
+                    totals.setdefault(name, {})[counter] = (launches, total)
+    best = None
+    for name, t in totals.items():
+        if 'FETCH_SIZE' not in t or 'WRITE_SIZE' not in t:
+            continue
+        launches = t['FETCH_SIZE'][0]
+        per_launch = (2 * t['FETCH_SIZE'][1] + t['WRITE_SIZE'][1]) * 1024 / launches
+        if best is None or per_launch * launches > best[1] * best[2]:
+            best = (name, per_launch, launches)
+    if best is None:
+        return None, 'no GEMM kernel found in the PMC databases'
+    return best[1], (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / '
+                     f'WRITE_SIZE (two child passes of one {args.chunk}-neuron step), '
+                     f'kernel with the most traffic = {best[0][:70]} ({best[2]} launches); '
+                     'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch')
 
 
 def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
@@ -242,7 +373,7 @@ def main():
                     help='vocabulary tokens (V = vocab + 4 specials)')
     ap.add_argument('--strategy', default='rerank',
                     choices=['greedy', 'beam', 'rerank'])
-    ap.add_argument('--cpu-sample', type=int, default=8,
+    ap.add_argument('--cpu-sample', type=int, default=32,
                     help='neurons for the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-profile', action='store_true',
                     help='do not bracket GEMM launches / stages with HIP events')
@@ -258,6 +389,10 @@ def main():
     ap.add_argument('--also-f32-steps', type=int, default=8,
                     help='extra timed steps in f32 mode, reported under '
                     '"f32_mode" (0 = skip)')
+    ap.add_argument('--live-traffic', type=int, default=1,
+                    help='1: measure roofline.traffic in this run (two extra child '
+                    'passes under rocprofv3 --pmc, ~1 min each, single-GPU runs '
+                    'only); 0: quote the committed offline summary')
     ap.add_argument('--other-configs', type=int, default=1,
                     help='1: also time SURVEY 8(d) configs 1 and 2 (single-GPU '
                     'runs only)')
@@ -268,6 +403,12 @@ def main():
     # several gloo ranks sharing the single GPU of a test box
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
+
+    # roofline.traffic, measured live: two child passes of ONE step under rocprofv3
+    # --pmc, run FIRST -- before this process holds its 150 GB of workspace
+    live_traffic = None
+    if world == 1 and args.live_traffic and not args.no_profile:
+        live_traffic = measure_traffic_live(args)
 
     nv = args.vocab
     blocks = synthetic.RESNET_BLOCKS['resnet101']
@@ -289,6 +430,12 @@ def main():
     strong = args.neurons_total > 0
     if strong:
         lo, hi = sharding.partition(args.neurons_total, world, rank, align=16)
+        # a shard smaller than the chunk runs as ONE launch of its own size (rounded
+        # up to 64 so that every rank -- also a ragged last one -- warms up and times
+        # the same launch geometry): `--gpus 8 --neurons-total 4096` = one 512-neuron
+        # chunk per rank
+        biggest = -(-args.neurons_total // world)
+        args.chunk = min(args.chunk, max(64, -(-biggest // 64) * 64))
         starts = list(range(lo, hi, args.chunk))
         sizes = [min(args.chunk, hi - a) for a in starts]
     else:
@@ -350,6 +497,8 @@ def main():
         gemm_ms, gemm_flops, gemm_launches = hip.profile_read()
         stages = hip.profile_read_stages()
         hip.profile_enable(False)
+    rank_seconds = sharding.all_ranks(elapsed, device)
+    rank_neurons = sharding.all_ranks(float(my_neurons), device)
     elapsed = sharding.max_over_ranks(elapsed, device)
     if os.environ.get('MILAN_BENCH_DEBUG'):  # per-rank checksums on stderr
         def h(t):
@@ -495,12 +644,27 @@ def main():
                 all_tokens.cpu().numpy().tobytes()).hexdigest(),
         },
         'host_reconstruct_ms': reconstruct_ms,
+        # per rank (its own clock around its own steps): a straggler GPU is visible
+        'per_rank': {
+            'neurons': [int(x) for x in rank_neurons],
+            'seconds': rank_seconds,
+            'value': [n / t if t > 0 else 0.0
+                      for n, t in zip(rank_neurons, rank_seconds)],
+        },
     }
+    result['per_rank']['value_min'] = min(result['per_rank']['value'])
+    result['per_rank']['value_max'] = max(result['per_rank']['value'])
     # HBM bytes per launch of the dominant kernel: PMC counters need their own
     # rocprofv3 passes (tools/pmc_traffic.sh), so the figure is read from the
     # committed summary of those passes, not collected live.
     traffic_bytes, traffic_note = None, 'not collected (PMC needs separate rocprofv3 passes)'
-    for name in ('r2_hbm_traffic.json', 'r1_hbm_traffic.json'):
+    live_reason = None
+    if live_traffic is not None:
+        traffic_bytes, traffic_note = live_traffic
+        if traffic_bytes is None:
+            live_reason, traffic_note = traffic_note, None
+    for name in ([] if traffic_bytes is not None else
+                 ['r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.json']):
         tpath = REPO / 'profiles' / name
         if args.precision != 'f32' and tpath.exists():
             with open(tpath) as f:
@@ -509,7 +673,8 @@ def main():
             traffic_note = (
                 f"bytes per launch of {tj['dominant_kernel']} (FETCH_SIZE x2 "
                 f"gfx950 correction + WRITE_SIZE), offline rocprofv3 --pmc "
-                f"passes summarised in profiles/{tpath.name}")
+                f"passes summarised in profiles/{tpath.name}" +
+                (f"; not measured live: {live_reason}" if live_reason else ''))
             break
     if gemm_ms:
         g_alg = algorithmic_gflop(beam, rerank)
@@ -588,9 +753,23 @@ def main():
             return ctx.describe(images, masks, strategy, args.length, beam,
                                 False, args.temperature, want_features=True)
 
+        def gpu_encode_modes(images, masks):
+            out = {}
+            for mode in dict.fromkeys((args.precision, 'f32', 'split_f16')):
+                ctx.set_precision(mode)
+                out[mode] = ctx.describe(images, masks, hip.GREEDY, 1, 1, False,
+                                         args.temperature,
+                                         want_features=True)['features']
+            ctx.set_precision(args.precision)
+            return out
+
+        def gpu_config1(images, masks):
+            return ctx.describe(images, masks, hip.GREEDY, args.length, 1, False,
+                                args.temperature, group_size=16)
+
         result['cpu_baseline'] = cpu_baseline(
             sd, nv, beam, args.length, args.temperature, args.cpu_sample,
-            gpu_describe if rerank else None)
+            gpu_describe if rerank else None, gpu_encode_modes, gpu_config1)
     else:
         result['cpu_baseline'] = None
     print(json.dumps(result), flush=True)

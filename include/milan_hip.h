@@ -342,6 +342,37 @@ int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int
                               float* extremes, void* workspace,
                               size_t workspace_bytes, milan_stream stream);
 
+/* What RunningQuantile does when level 0 is full and the bulk call above stopped: one
+ * _shift() (runningstats.py:387-407) INCLUDING the _expand() it may end in
+ * (:485-529), as a plan -- host arithmetic only, no device work.  The caller executes
+ * the operations in order (on its own tensors) and adopts the returned fill counts:
+ *   MILAN_SKETCH_COMPACT  sort level `src`'s first n columns, keep every second one
+ *                         from `offset`, write them to level `dst` at `position`
+ *                         (milan_exemplar_sketch_compact; `extremes` != 0: fold min /
+ *                         max into the extremes);
+ *   MILAN_SKETCH_INSERT   a new, empty level 0 of `capacity` columns (every later
+ *                         level index in the plan counts it);
+ *   MILAN_SKETCH_MOVE     level `src`'s first n columns -> level `dst` at `position`;
+ *   MILAN_SKETCH_HALVE    the sample rate halves (no room for another level).
+ * Level indices are those at the moment the operation runs.  `draw_bit(user)` hands
+ * out the caller's random bits in the order upstream consumes them (torch's global
+ * generator, so that a seeded run reproduces the reference).  capacities_out /
+ * firstfree_out need room for n_levels + 1 entries. */
+enum { MILAN_SKETCH_COMPACT = 0, MILAN_SKETCH_INSERT = 1, MILAN_SKETCH_MOVE = 2,
+       MILAN_SKETCH_HALVE = 3 };
+typedef struct milan_sketch_op {
+  int32_t kind, src, dst, offset, extremes, reserved;
+  int64_t n, position, capacity;
+} milan_sketch_op;
+int milan_exemplar_sketch_plan_shift(int64_t resolution, int64_t buffersize,
+                                     int full_rate, int n_levels,
+                                     const int64_t* capacities,
+                                     const int64_t* firstfree,
+                                     int (*draw_bit)(void*), void* user,
+                                     milan_sketch_op* ops, int max_ops, int* n_ops,
+                                     int64_t* capacities_out, int64_t* firstfree_out,
+                                     int* n_levels_out);
+
 /* RunningQuantile.quantiles(q) for one q (runningstats.py:531-580): weighted
  * summary of all levels (level l has weight 2^l), stable sort, float32
  * cumulative weights, numpy.interp in float64 -> out [n_units] float32.

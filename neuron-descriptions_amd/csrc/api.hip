@@ -392,6 +392,9 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
   // precision 2 (test hook only): split-f16 with the LDS-strip 3x3 kernel forced
   const bool force_strip = precision == 2;
   if (force_strip) precision = MILAN_PRECISION_SPLIT_F16;
+  MILAN_REQUIRE(!force_strip || MILAN_EXPERIMENTS, MILAN_ERR_ARG,
+                "conv2d: the LDS-strip 3x3 kernel is only in an experiments build "
+                "(make EXPERIMENTS=1)");
   MILAN_REQUIRE(precision == MILAN_PRECISION_F32 || cin % 32 == 0,
                 MILAN_ERR_SHAPE, "conv2d: split-f16 needs cin %% 32 == 0");
   MILAN_REQUIRE(cin % 4 == 0 && n > 0 && cout > 0, MILAN_ERR_SHAPE,
@@ -426,7 +429,8 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
           r = split_weight_into(wp, cout, Kp, wsp, &g.acc_scale,
                                 reinterpret_cast<unsigned int*>(zero) + 32, s);
         g.A = xs; g.W = wsp; g.a_split = 1;
-        if (r == 0 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && K == Kp) {
+        if (MILAN_EXPERIMENTS && r == 0 && kh == 3 && kw == 3 && stride == 1 &&
+            pad == 1 && K == Kp) {
           // the trunk's 3x3 convs run on the LDS-strip kernel: test it the same way
           if (hipMalloc((void**)&ws3, sizeof(float) * (size_t)cout * Kp) == hipSuccess) {
             r = make_chunk_major(wsp, cout, cin, ws3, s);

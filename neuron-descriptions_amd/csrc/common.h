@@ -9,6 +9,12 @@
 
 #include "../../include/milan_hip.h"
 
+// experiments build (make EXPERIMENTS=1): measured-and-rejected kernels and the
+// knobs that force tile configurations; see gemm.hip and DESIGN.md section 5
+#ifndef MILAN_EXPERIMENTS
+#define MILAN_EXPERIMENTS 0
+#endif
+
 namespace milan {
 
 // ---- error plumbing (no C++ exceptions cross the C ABI) --------------------
@@ -93,8 +99,6 @@ struct GemmArgs {
                       // experiments: 1 / 2 the round-1 256x128x3 / 128x128x2 kernels, 3 / 4 / 5
                       // split16 256x256x4 / 256x128x3 / 128x256x3, 6 / 10 N <= 64 on / off the
                       // 64x64-wave-tile split16 kernel, 8 the LDS-strip 3x3 kernel
-  int stagger;        // experiment: first-round workgroups with an odd per-XCD index start
-                      // this many microseconds late (phase-shifts neighbouring CUs)
   float* C2;          // EPI_LSTM: new cell state
   float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
 };
@@ -102,9 +106,6 @@ struct GemmArgs {
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2 };
 
 int launch_gemm(const GemmArgs& g, hipStream_t s);
-// a and b in one launch when both run on the 256x256 split16 kernel (tiles
-// interleaved; see igemm_split16_pair_kernel), otherwise one after the other
-int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 // rows x K fp32 (row stride ld_src) -> split format (row stride ld_dst), x scale
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
                         long rows, int K, float scale, hipStream_t s);

@@ -146,6 +146,7 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
   if ((g || split_without_bn) && out->cin % 32 == 0) {  // split-f16 copy
     MILAN_TRY(make_split_weight(c, out->w, out->cout, out->Kp, &out->ws,
                                 &out->ws_inv, s));
+#if MILAN_EXPERIMENTS
     if (out->ws && out->kh == 3 && out->kw == 3 && out->stride == 1 &&
         out->pad == 1 && out->Kp == out->K) {
       // chunk-major copy for the LDS-strip 3x3 kernel: 32-byte groups of 8
@@ -154,6 +155,7 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
                           sizeof(float) * (size_t)out->cout * out->Kp));
       MILAN_TRY(make_chunk_major(out->ws, out->cout, out->cin, out->ws3, s));
     }
+#endif
   }
   return 0;
 }
@@ -742,21 +744,6 @@ static int encoder_sub_batch() {
   return v;
 }
 
-// MILAN_ENC_PIPELINE=1: two-half software pipeline over the late stages (see
-// encoder_run_batch).  MEASURED in round 2 and kept OFF: bitwise identical
-// results, but layer3 takes 127.5 ms instead of 123.2 per 256-neuron pass -- the
-// expand convs' epilogues already run at the practical HBM rate when every CU
-// is in one (4.75 TB/s), and interleaving a second problem's tiles costs more
-// in L2 residency of the two weight sets than the phase mixing returns.
-static bool encoder_pipeline_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MILAN_ENC_PIPELINE");
-    v = e ? (atoi(e) != 0) : 0;
-  }
-  return v != 0;
-}
-
 static void alexnet_workspace_dry(const milan_ctx* c, int n, int H, int W,
                                   Arena& a);
 
@@ -986,23 +973,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   // 4. bottleneck stages; tap after each stage
   float *x = pl.x0, *y = pl.x1;
   int h = pl.hp, w = pl.wp, col = wd;
-  // Stages whose convolutions all run on the 256x256 split16 kernel (layer3 and
-  // layer4 of the 64-wide ResNets) are executed as a two-half software
-  // pipeline (encoder_pipelined_stages below); the loop here stops before them.
-  int first_pipelined = 4;
-  if (split && !spatial && n >= 2 && c->d.trunk_kind == MILAN_TRUNK_BOTTLENECK &&
-      encoder_pipeline_enabled()) {
-    first_pipelined = 4;
-    for (int li = 3; li >= 1; --li) {
-      bool ok = true;
-      for (const Bottleneck& b : c->blocks[li])
-        ok = ok && b.c1.cout % 256 == 0 && b.c1.cin % 32 == 0 &&
-             (!b.has_down || b.c3d.ws != nullptr);
-      if (!ok) break;
-      first_pipelined = li;
-    }
-  }
-  for (int li = 0; li < first_pipelined; ++li) {
+  for (int li = 0; li < 4; ++li) {
     stage.emplace(MILAN_STAGE_ENC_LAYER1 + li, s);
     // t1_ready: pl.t1 already holds this block's c1 output -- the previous block's
     // expand conv and this block's reduce conv ran as one launch (chain.hip)
@@ -1108,101 +1079,6 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                   "internal: stage %d geometry mismatch", li + 1);
     MILAN_TRY(pool(x, li + 1, C, col));
     col += C;
-  }
-  if (first_pipelined < 4) {
-    // ---- two-half software pipeline over the late stages ---------------------
-    // The batch is split into halves A and B that run the same chain of
-    // convolutions one op apart: launch j holds op j of A and op j-1 of B in ONE
-    // grid (launch_gemm_pair).  Consecutive ops of a bottleneck alternate
-    // between matrix-core-bound (1x1 reduce, 3x3) and HBM-bound (1x1 expand:
-    // residual read + 4x wider store), so every launch mixes the two kinds and
-    // the expand convs' epilogues overlap the other half's MFMA loops.  Results
-    // are bitwise those of the plain schedule (same kernel, same tiles per
-    // output row).  Half B's tensors live nA * (buffer extent per image) into
-    // each buffer, so the halves never touch each other's rows.
-    struct Op {
-      bool is_pool = false;
-      GemmArgs g{};
-      const float* tap = nullptr; int level = 0, C = 0, col = 0, img0 = 0, cnt = 0;
-      int stage = 0;
-    };
-    const int nA = n / 2, nB = n - nA;
-    auto gen = [&](int img0, int cnt, std::vector<Op>& ops) -> int {
-      // this half's input: the dense tensor the previous stages left in x
-      const float* in = x + (size_t)img0 * h * w *
-                                ((size_t)c->blocks[first_pipelined][0].c1.cin);
-      float* bx = x;  // buffer holding the current tensor
-      float* by = y;
-      int hh = h, ww = w, ccol = col;
-      for (int li = first_pipelined; li < 4; ++li) {
-        for (const Bottleneck& b : c->blocks[li]) {
-          int h1, w1, h2, w2, h3, w3;
-          float* t1 = pl.t1 + (size_t)img0 * pl.t1_sz;
-          float* t2 = pl.t2 + (size_t)img0 * pl.t2_sz;
-          float* out = by + (size_t)img0 * pl.x_sz;
-          Op o1, o2, o3;
-          o1.stage = o2.stage = o3.stage = MILAN_STAGE_ENC_LAYER1 + li;
-          o1.g = conv_args(b.c1, in, cnt, hh, ww, t1, EPI_BIAS_RELU, nullptr,
-                           c->zero, &h1, &w1, true);
-          o2.g = conv_args(b.c2, t1, cnt, h1, w1, t2, EPI_BIAS_RELU, nullptr,
-                           c->zero, &h2, &w2, true);
-          if (b.has_down) {
-            // c3 and the downsample as ONE GEMM over [t2 | x(strided)]
-            o3.g = conv_args(b.c3d, t2, cnt, h2, w2, out, EPI_BIAS_RELU, nullptr,
-                             c->zero, &h3, &w3, true);
-            o3.g.Cin = b.c3.cin;
-            o3.g.a_pix_stride = b.c3.cin;
-            o3.g.a_img_stride = (long)h2 * w2 * b.c3.cin;
-            o3.g.A2 = in; o3.g.K1 = b.c3.K; o3.g.H2 = hh; o3.g.W2d = ww;
-            o3.g.stride2 = b.down.stride;
-            o3.g.a2_pix_stride = b.down.cin;
-            o3.g.a2_img_stride = (long)hh * ww * b.down.cin;
-            o3.g.flop_k = b.c3.K + b.down.K;
-          } else {
-            o3.g = conv_args(b.c3, t2, cnt, h2, w2, out, EPI_BIAS_RES_RELU, in,
-                             c->zero, &h3, &w3, true);
-          }
-          ops.push_back(o1); ops.push_back(o2); ops.push_back(o3);
-          in = out;
-          float* tmp = bx; bx = by; by = tmp;
-          hh = h3; ww = w3;
-        }
-        const int C = (wd * 4) << li;
-        MILAN_REQUIRE(hh == pl.lv.h[li + 1] && ww == pl.lv.w[li + 1],
-                      MILAN_ERR_SHAPE, "internal: stage %d geometry mismatch",
-                      li + 1);
-        Op pp;
-        pp.is_pool = true; pp.tap = in; pp.level = li + 1; pp.C = C;
-        pp.col = ccol; pp.img0 = img0; pp.cnt = cnt;
-        pp.stage = MILAN_STAGE_ENC_LAYER1 + li;
-        ops.push_back(pp);
-        ccol += C;
-      }
-      return 0;
-    };
-    std::vector<Op> opsA, opsB;
-    MILAN_TRY(gen(0, nA, opsA));
-    MILAN_TRY(gen(nA, nB, opsB));
-    const size_t L = opsA.size();
-    for (size_t j = 0; j <= L; ++j) {
-      const Op* a = j < L ? &opsA[j] : nullptr;
-      const Op* b = j >= 1 ? &opsB[j - 1] : nullptr;
-      if (a && b && !a->is_pool && !b->is_pool) {
-        StageScope scope(a->stage, s);  // (B's op is one step behind)
-        MILAN_TRY(launch_gemm_pair(a->g, b->g, s));
-        continue;
-      }
-      for (const Op* o : {a, b}) {
-        if (!o) continue;
-        if (o->is_pool) {
-          MILAN_TRY(pool(o->tap, o->level, o->C, o->col, o->img0, o->cnt));
-        } else {
-          StageScope scope(o->stage, s);
-          MILAN_TRY(launch_gemm(o->g, s));
-        }
-      }
-    }
-    return 0;
   }
   if (spatial) {
     // layer4 output, NHWC == the reference's permute(0, 2, 3, 1): (n, h*w, C)

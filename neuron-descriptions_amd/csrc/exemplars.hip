@@ -15,6 +15,9 @@
 // the reference; the kernels below are its tensor operations.
 #include "common.h"
 
+#include <cmath>
+#include <algorithm>
+
 #include <vector>
 #include <hipcub/hipcub.hpp>
 
@@ -749,6 +752,89 @@ int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int
   for (int l = 0; l < n_levels; ++l) firstfree[l] = ff[l];
   *currentbit = bit;
   *consumed = index;
+  return 0;
+}
+
+// Host-only planner of one "make room in level 0" step of the sketch (see the header).
+// Restates RunningQuantile._shift / _expand / _next_capacity of the vendored
+// netdissect (src/deps/netdissect/runningstats.py:387-407, 485-529) as a function from
+// (capacities, fill counts, random bits) to a list of operations.
+int milan_exemplar_sketch_plan_shift(int64_t resolution, int64_t buffersize,
+                                     int full_rate, int n_levels,
+                                     const int64_t* capacities,
+                                     const int64_t* firstfree,
+                                     int (*draw_bit)(void*), void* user,
+                                     milan_sketch_op* ops, int max_ops, int* n_ops,
+                                     int64_t* capacities_out, int64_t* firstfree_out,
+                                     int* n_levels_out) {
+  MILAN_REQUIRE(capacities && firstfree && draw_bit && ops && n_ops &&
+                    capacities_out && firstfree_out && n_levels_out,
+                MILAN_ERR_ARG, "sketch_plan_shift: null argument");
+  MILAN_REQUIRE(n_levels >= 1 && n_levels <= 64 && max_ops >= 2 * n_levels + 4,
+                MILAN_ERR_SHAPE, "sketch_plan_shift: bad sizes");
+  std::vector<int64_t> cap(capacities, capacities + n_levels);
+  std::vector<int64_t> fill(firstfree, firstfree + n_levels);
+  int count = 0;
+  auto emit = [&](int kind, int src, int dst, int64_t n, int offset, int64_t position,
+                  int extremes, int64_t capacity) {
+    ops[count++] = milan_sketch_op{kind, src, dst, offset, extremes, 0, n, position,
+                                   capacity};
+  };
+  // a level must keep room for half of the level below it (level 0: one sample)
+  auto wanted = [&](size_t level) -> int64_t {
+    return level ? (cap[level - 1] + 1) / 2 : 1;
+  };
+  auto halved = [](int64_t n, int offset) { return (n - offset + 1) / 2; };
+  size_t level = 0;
+  bool grow = false;
+  while (cap[level] - fill[level] < wanted(level)) {
+    if (level + 1 >= cap.size()) { grow = true; break; }
+    const int offset = draw_bit(user) ? 1 : 0;
+    emit(MILAN_SKETCH_COMPACT, (int)level, (int)level + 1, fill[level], offset,
+         fill[level + 1], level == 0 && full_rate, 0);
+    fill[level + 1] += halved(fill[level], offset);
+    fill[level] = 0;
+    ++level;
+  }
+  if (grow) {
+    // capacity of one more level: the resolution shrunk by 0.67 per existing level,
+    // in steps of 8, not below the buffer size; under 2 there is no further level
+    int64_t fresh = (int64_t)std::ceil((double)resolution *
+                                       std::pow(0.67, (double)cap.size()));
+    fresh = fresh < 2 ? 0 : std::max<int64_t>(buffersize, (fresh + 7) / 8 * 8);
+    if (fresh > 0) {
+      emit(MILAN_SKETCH_INSERT, 0, 0, 0, 0, 0, 0, fresh);
+      cap.insert(cap.begin(), fresh);
+      fill.insert(fill.begin(), 0);
+    } else {
+      MILAN_REQUIRE(fill[0] == 0, MILAN_ERR_STATE, "sketch_plan_shift: level 0 not empty");
+      emit(MILAN_SKETCH_HALVE, 0, 0, 0, 0, 0, 0, 0);
+    }
+    // every level hands its content one level down where that level has the room,
+    // and is compacted in place where it has not
+    for (size_t upper = 1; upper < cap.size(); ++upper) {
+      const int64_t amount = fill[upper];
+      if (amount == 0) continue;
+      const size_t lower = upper - 1;
+      if (cap[lower] - (fill[lower] + amount) >= wanted(lower)) {
+        emit(MILAN_SKETCH_MOVE, (int)upper, (int)lower, amount, 0, fill[lower], 0, 0);
+        fill[lower] += amount;
+        fill[upper] = 0;
+      } else {
+        const int offset = draw_bit(user) ? 1 : 0;
+        emit(MILAN_SKETCH_COMPACT, (int)upper, (int)upper, amount, offset, 0,
+             upper == 1, 0);
+        fill[upper] = halved(amount, offset);
+      }
+    }
+  }
+  MILAN_REQUIRE(count <= max_ops, MILAN_ERR_SHAPE, "sketch_plan_shift: plan too long");
+  *n_ops = count;
+  *n_levels_out = (int)cap.size();
+  for (size_t l = 0; l < cap.size(); ++l) {
+    capacities_out[l] = cap[l];
+    firstfree_out[l] = fill[l];
+  }
   return 0;
 }
 

@@ -49,6 +49,14 @@
 #ifndef MILAN_ABLATE_BUILD
 #define MILAN_ABLATE_BUILD 0
 #endif
+// Kernels and knobs that were measured and LOST (the LDS-strip 3x3 conv, the
+// two-problem "pair" launch, issue-slot shaping, forced tile configurations) are
+// compiled only into an experiments build (make EXPERIMENTS=1); the product library
+// carries the winning configuration per layer shape and nothing else.  Table of knobs:
+// DESIGN.md section 5.
+#ifndef MILAN_EXPERIMENTS
+#define MILAN_EXPERIMENTS 0
+#endif
 
 namespace milan {
 
@@ -661,13 +669,6 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  if (g.stagger > 0 && blockIdx.x < (NT >= 512 ? 256 : 512) && ((blockIdx.x >> 3) & 1)) {
-    // s_memrealtime ticks at 100 MHz
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)g.stagger * 100ull)
-      __builtin_amdgcn_s_sleep(32);
-  }
-
   // loader: NT threads cover NT/4 rows x 4 chunks per pass
   const int lrow = tid >> 2;                        // 0..LROWS-1
   const int kc = (tid & 3) ^ ((tid >> 4) & 3);      // (row>>2)&3 == (tid>>4)&3
@@ -822,7 +823,7 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
             as_f16x8(ah[i]), as_f16x8(bh[j]), acc[i][j], 0, 0, 0);
       }
     }
-    if constexpr (SHAPE == 1) {
+    if constexpr (MILAN_EXPERIMENTS && SHAPE == 1) {
       // issue-slot shaping: fragments of the first row-tile, then one MFMA
       // followed by a few of the remaining non-MFMA instructions, repeated
       __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // DS_READ
@@ -899,44 +900,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_split16_t
   split16_tile<BM, BN, STAGES, 0, 2>(g, tile_m, tile - tile_m * tiles_n);
 }
 
-// Two independent problems in ONE launch, their tiles interleaved in proportion
-// on every XCD.  Used by the encoder to run a bandwidth-bound convolution of one
-// half of the batch (the 1x1 expand convs: residual read + full-width store)
-// next to a matrix-core-bound one of the other half (the 3x3 / 1x1 reduce
-// convs), so that the HBM-bound epilogues of the first overlap the MFMA main
-// loops of the second on the chip instead of every CU hitting the same phase.
-struct GemmPair {
-  GemmArgs g[2];
-  int tiles_m[2], tiles_n[2];
-};
 
-__device__ __forceinline__ void xcd_range(int T, int xcd, int* start, int* count) {
-  const int q = T >> 3, r = T & 7;
-  *count = q + (xcd < r ? 1 : 0);
-  *start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-}
-
-template <int BM, int BN, int STAGES>
-__global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_pair_kernel(
-    GemmPair p) {
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  int s0, c0, s1, c1;
-  xcd_range(p.tiles_m[0] * p.tiles_n[0], xcd, &s0, &c0);
-  xcd_range(p.tiles_m[1] * p.tiles_n[1], xcd, &s1, &c1);
-  if (j >= c0 + c1) return;  // grid is padded to 8 * max per-XCD count
-  // Bresenham interleave: a(j) = floor(j c0 / (c0 + c1)) problem-0 tiles precede
-  // local slot j
-  const int a0 = (int)((long)j * c0 / (c0 + c1));
-  const int a1 = (int)((long)(j + 1) * c0 / (c0 + c1));
-  const int which = a1 > a0 ? 0 : 1;
-  const int tile = which == 0 ? s0 + a0 : s1 + (j - a0);
-  const GemmArgs& g = p.g[which];
-  const int tn = p.tiles_n[which];
-  const int tile_m = tile / tn;
-  split16_tile<BM, BN, STAGES, 0>(g, tile_m, tile - tile_m * tn);
-}
-
-
+#if MILAN_EXPERIMENTS
 // ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with the input strip resident in LDS.
 //
@@ -1190,6 +1155,8 @@ static int launch_conv3x3(const GemmArgs& g, hipStream_t s) {
   return 0;
 }
 
+#endif  // MILAN_EXPERIMENTS (LDS-strip 3x3 kernel)
+
 // ---------------------------------------------------------------------------
 // fp32 <-> split-format conversion of a row-major matrix (rows x K, K % 8 == 0)
 // ---------------------------------------------------------------------------
@@ -1426,9 +1393,11 @@ static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
 
 template <int BM, int BN, int STAGES>
 static int launch_split16(const GemmArgs& g, hipStream_t s) {
+#if MILAN_EXPERIMENTS
   static int shape = -1;
   if (shape < 0) { const char* e = getenv("MILAN_SCHED"); shape = e ? atoi(e) : 0; }
   if (shape == 1) return launch_split16_impl<BM, BN, STAGES, 1>(g, s);
+#endif
   return launch_split16_impl<BM, BN, STAGES, 0>(g, s);
 }
 
@@ -1436,6 +1405,7 @@ static bool aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
 
+#if MILAN_EXPERIMENTS
 static int env_tile_hint() {
   static int v = -1;
   if (v < 0) {
@@ -1484,6 +1454,11 @@ static bool conv3x3_enabled() {
   return v != 0;
 }
 
+#else
+static int env_tile_hint() { return 0; }
+static int env_tile_override(int, int) { return 0; }
+#endif
+
 static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   const bool cin32 = (g.Cin % 32 == 0);
   if (g.tile_hint == 0) g.tile_hint = env_tile_hint();
@@ -1492,10 +1467,6 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("MILAN_ABLATE"); dbg = e ? atoi(e) : 0; }
     g.debug = dbg;  // 1: skip MFMA phase, 2: skip DMA (timing experiments only)
-    static int stg = -1;
-    if (stg < 0) { const char* e = getenv("MILAN_STAGGER"); stg = e ? atoi(e) : 0; }
-    // the expand convs (residual / two-source epilogue-heavy launches)
-    g.stagger = (g.out_split && g.N >= 256 && g.KH == 1 && g.H > 1 && (g.aux || g.A2)) ? stg : 0;
   }
   // pick the epilogue form
   if (g.epilogue == EPI_LSTM) {
@@ -1553,6 +1524,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
         (g.tile_hint == 6 || (g.tile_hint == 0 && g.KH * g.KW > 1)))
       return launch_split16_tm2<256, 64, 3>(g, s);
     if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
+#if MILAN_EXPERIMENTS
     // 3x3 / stride 1 with the chunk-major weight copy: input strip in LDS
     if (g.W3 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.A2 &&
         g.Cin % 16 == 0 && g.a_pix_stride == g.Cin && g.Ho == g.H && g.Wo == g.Wd &&
@@ -1561,6 +1533,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
       if (g.N % 256 == 0) return launch_conv3x3<256>(g, s);
       if (g.N % 128 == 0) return launch_conv3x3<128>(g, s);
     }
+#endif
     // Measured on the 4096-neuron workload (profiles/): the 4-wave 256x128
     // tile with 16-slot k-tiles, a 3-deep ring and DMA pieces interleaved with
     // the MFMA groups (2 workgroups per CU) is the fastest split-mode
@@ -1570,11 +1543,13 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     // of rows: different tile configurations accumulate in different orders,
     // and a description must not depend on how many neurons shared its launch
     // (chunk size, world size).  Short M just leaves tile rows masked.
+#if MILAN_EXPERIMENTS
     if (g.tile_hint == 3) return launch_split16<256, 256, 4>(g, s);
     if (g.tile_hint == 4) return launch_split16<256, 128, 3>(g, s);
     if (g.tile_hint == 5) return launch_split16<128, 256, 3>(g, s);
     if (g.tile_hint == 1) return launch_cfg<256, 128, 3, true, true>(g, s);
     if (g.tile_hint == 2) return launch_cfg<128, 128, 2, true, true>(g, s);
+#endif
     if (g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);
     {
       // wide outputs that are not a multiple of 256 (the vocabulary GEMMs, N =
@@ -1594,80 +1569,12 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   }
   // (the 8-wave 3-stage tile measured 4% slower than 128x128x2 in F32 mode,
   // where one k-tile is 4096 MFMA cycles and latency is already hidden)
+#if MILAN_EXPERIMENTS
   if (cin32 && g.tile_hint == 1)
     return launch_cfg<256, 128, 3, true, false>(g, s);
+#endif
   return cin32 ? launch_cfg<128, 128, 2, true, false>(g, s)
                : launch_cfg<128, 128, 2, false, false>(g, s);
-}
-
-// true when launch_gemm would run g on the 256x256x4 split16 kernel
-static bool uses_split16_256(const GemmArgs& g) {
-  return g.a_split && g.Cin % 32 == 0 && g.N > 64 && g.N % 256 == 0 && !g.W3 &&
-         g.tile_hint == 0 && env_tile_hint() == 0 &&
-         env_tile_override(g.N, g.K) == 0;
-}
-
-static int finish_args(GemmArgs& g) {  // what launch_gemm_impl derives
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("MILAN_ABLATE"); dbg = e ? atoi(e) : 0; }
-  g.debug = dbg;
-  MILAN_REQUIRE(g.out_split && g.N % 8 == 0 && g.ldc % 8 == 0 && aligned16(g.C) &&
-                    (g.bias == nullptr || aligned16(g.bias)) &&
-                    (g.aux == nullptr ||
-                     (g.aux_split && g.ldaux % 8 == 0 && aligned16(g.aux))),
-                MILAN_ERR_SHAPE, "gemm pair: needs split-format outputs");
-  g.out_mode = OUT_SPLIT8;
-  if (g.acc_scale == 0.f) g.acc_scale = 1.f;
-  return 0;
-}
-
-int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("MILAN_GEMM_PAIR"); off = e && atoi(e) == 0; }
-  if (off || !uses_split16_256(a) || !uses_split16_256(b) || !a.out_split ||
-      !b.out_split) {
-    MILAN_TRY(launch_gemm(a, s));
-    return launch_gemm(b, s);
-  }
-  constexpr int BM = 256, BN = 256, STAGES = 4;
-  GemmPair p;
-  p.g[0] = a; p.g[1] = b;
-  int per_xcd = 0;
-  for (int i = 0; i < 2; ++i) {
-    MILAN_TRY(finish_args(p.g[i]));
-    p.tiles_m[i] = (p.g[i].M + BM - 1) / BM;
-    p.tiles_n[i] = (p.g[i].N + BN - 1) / BN;
-  }
-  per_xcd = (p.tiles_m[0] * p.tiles_n[0] + 7) / 8 + (p.tiles_m[1] * p.tiles_n[1] + 7) / 8;
-  constexpr int NT = (BM / 128) * (BN / 64) * 64;
-  const size_t lds = size_t(STAGES) * (BM + BN) * 16 * sizeof(float);
-  auto kern = igemm_split16_pair_kernel<BM, BN, STAGES>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kern),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  ProfRec* e = nullptr;
-  if (g_prof.on) {
-    e = prof_next();
-    MILAN_REQUIRE(e != nullptr, MILAN_ERR_STATE, "profiler: cannot create events");
-    e->stage = g_prof.stage;
-    e->gemm = true;
-    e->flops = 0.0;
-    e->bytes = 0.0;
-    for (int i = 0; i < 2; ++i) {
-      e->flops += 2.0 * (double)p.g[i].M * (double)p.g[i].N *
-                  (double)(p.g[i].flop_k > 0 ? p.g[i].flop_k : p.g[i].K);
-      e->bytes += gemm_algorithmic_bytes(p.g[i]);
-    }
-    MILAN_CHECK_HIP(hipEventRecord(e->a, s));
-  }
-  hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(NT), lds, s, p);
-  MILAN_CHECK_HIP(hipGetLastError());
-  if (e) MILAN_CHECK_HIP(hipEventRecord(e->b, s));
-  return 0;
 }
 
 int launch_gemm(const GemmArgs& g, hipStream_t s) {

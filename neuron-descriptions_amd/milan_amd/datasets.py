@@ -221,3 +221,40 @@ def load(key: str, path: Optional[Union[str, pathlib.Path]] = None,
     if not root.exists():
         raise KeyError(f'unknown milannotations set: {key}')
     return TopImagesDataset(root, name=key, **kwargs)
+
+
+class ShardView(data.Dataset):
+    """Samples [lo, hi) of a `TopImagesDataset`, as one rank of a sharded job sees
+    them (scripts/compute_milan_descriptions.py).  Unlike `data.Subset` it keeps what
+    `Decoder.predict` looks at to choose its ingest path: the dataset-side
+    `transform_images` / `transform_masks` / `device` attributes, and
+    `slice_uint8(lo, hi, out=)` -- the one-pass copy from the memory maps into the
+    prefetcher's pinned staging buffers."""
+
+    def __init__(self, dataset: TopImagesDataset, lo: int, hi: int):
+        if not 0 <= lo <= hi <= len(dataset):
+            raise IndexError(f'shard [{lo}, {hi}) outside dataset of '
+                             f'{len(dataset)} samples')
+        self.dataset, self.lo, self.hi = dataset, lo, hi
+
+    # what predict()'s fast-path guard reads
+    transform_images = property(lambda self: self.dataset.transform_images)
+    transform_masks = property(lambda self: self.dataset.transform_masks)
+    device = property(lambda self: self.dataset.device)
+
+    def __len__(self) -> int:
+        return self.hi - self.lo
+
+    def __getitem__(self, index: int):
+        if not -len(self) <= index < len(self):
+            raise IndexError(f'sample index out of bounds: {index}')
+        return self.dataset[self.lo + index % len(self)]
+
+    def unit(self, index: int):
+        return self.dataset.unit(self.lo + index)
+
+    def slice_uint8(self, lo: int, hi: int, out=None):
+        if not 0 <= lo <= hi <= len(self):
+            raise IndexError(f'slice [{lo}, {hi}) outside shard of '
+                             f'{len(self)} samples')
+        return self.dataset.slice_uint8(self.lo + lo, self.lo + hi, out=out)

@@ -508,6 +508,19 @@ class Decoder(nn.Module):
             # compute hides, and a chunk's compute has to cover the next
             # chunk's fetch (results do not depend on how neurons are grouped
             # into launches).
+            if n > 0:
+                # no more neurons per launch than the free memory carries, and ONE
+                # workspace allocation at the largest chunk instead of one per
+                # ramp step
+                probe_im, _ = fast(0, 1)
+                ctx = self._context()
+                args = (probe_im.shape[1], max(probe_im.shape[-2:]),
+                        kwargs.get('beam_size') or self.beam_size,
+                        kwargs.get('length') or self.length)
+                chunk = max(batch_size,
+                            ctx.fit_neurons(min(chunk, n), args[0], *args[1:],
+                                            multiple=batch_size))
+                ctx.workspace(min(chunk, n), *args)
             spans, lo, size = [], 0, batch_size * max(1, 64 // batch_size)
             while lo < n:
                 size = min(size, chunk)

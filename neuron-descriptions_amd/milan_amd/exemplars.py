@@ -64,6 +64,34 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _normalise_units(units: Sequence[int], channels: int):
+    """Unit indices as `pooled[:, units]` reads them (compute.py:331-333): negative
+    ones count from the end, out-of-range ones raise IndexError."""
+    out = []
+    for unit in units:
+        unit = int(unit)
+        if not -channels <= unit < channels:
+            raise IndexError(f'index {unit} is out of bounds for dimension 1 '
+                             f'with size {channels}')
+        out.append(unit % channels)
+    return out
+
+
+def _checked_units(owner, units: Optional[torch.Tensor], channels: int):
+    """Validate a device tensor of unit indices once per (tensor, channels): the
+    kernels index `units[u]` without a bounds check."""
+    if units is None:
+        return None
+    key = (units.data_ptr(), len(units), channels)
+    cache = owner.__dict__.setdefault('_units_checked', {})
+    if key not in cache:
+        host = units.detach().cpu().tolist()
+        norm = _normalise_units(host, channels)
+        cache[key] = units if norm == host else torch.tensor(
+            norm, dtype=torch.int32, device=units.device)
+    return cache[key]
+
+
 def _as_hiddens(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -92,6 +120,7 @@ class RunningTopK:
         hiddens = _as_hiddens(hiddens)
         device = hip.require_device(hiddens.device)
         batch, channels = hiddens.shape[:2]
+        units = _checked_units(self, units, channels)
         hw = int(numpy.prod(hiddens.shape[2:])) if hiddens.dim() > 2 else 1
         n_units = channels if units is None else len(units)
         if self.values is None:
@@ -190,6 +219,7 @@ class RunningQuantile:
         one sample per unit (compute.py:329-330)."""
         hiddens = _as_hiddens(hiddens)
         batch, channels = hiddens.shape[:2]
+        units = _checked_units(self, units, channels)
         hw = int(numpy.prod(hiddens.shape[2:])) if hiddens.dim() > 2 else 1
         depth = channels if units is None else len(units)
         if self.depth is None:
@@ -214,7 +244,7 @@ class RunningQuantile:
             ff = self.firstfree[0]
             available = self.data[0].shape[1] - ff
             if available == 0:
-                if not self._shift():
+                if not self._make_room():
                     raise NotImplementedError(
                         'RunningQuantile subsampling regime is not built')
                 ff = self.firstfree[0]
@@ -260,65 +290,50 @@ class RunningQuantile:
         assert incoming.dim() == 2
         self.add_hiddens(incoming)
 
-    def _randbit(self) -> int:
+    def _draw(self, _user=None) -> int:
+        """Next random bit, from torch's global generator in blocks of `resolution`
+        (so that a seeded run consumes it like the reference does).  The bulk call
+        reads the same block through `randbits` / `currentbit`."""
         self.currentbit += 1
         if self.currentbit >= len(self.randbits):
-            self.randbits.random_(to=2)  # torch's global generator, as upstream
+            self.randbits.random_(to=2)
             self.currentbit = 0
         return int(self.randbits[self.currentbit])
 
-    def _shift(self) -> bool:  # runningstats.py:387-407
-        index = 0
-        while self.data[index].shape[1] - self.firstfree[index] < (
-                -(-self.data[index - 1].shape[1] // 2) if index else 1):
-            if index + 1 >= len(self.data):
-                return self._expand()
-            n = self.firstfree[index]
-            offset = self._randbit()
-            position = self.firstfree[index + 1]
-            moved = self._compact(self.data[index], n, offset,
-                                  self.data[index + 1], position,
-                                  extremes=(index == 0 and
-                                            self.samplerate >= 1.0))
-            self.firstfree[index] = 0
-            self.firstfree[index + 1] += moved
-            index += 1
-        return True
-
-    def _next_capacity(self) -> int:  # :523-529
-        cap = int(math.ceil(self.resolution * (0.67**len(self.data))))
-        if cap < 2:
-            return 0
-        cap = -8 * (-cap // 8)
-        return max(self.buffersize, cap)
-
-    def _expand(self) -> bool:  # :485-521
-        cap = self._next_capacity()
-        if cap > 0:
-            self.data.insert(0, torch.zeros(self.depth, cap,
-                                            device=self.device))
-            self.firstfree.insert(0, 0)
-        else:
-            assert self.firstfree[0] == 0
-            self.samplerate *= 0.5
-        for index in range(1, len(self.data)):
-            amount = self.firstfree[index]
-            if amount == 0:
-                continue
-            position = self.firstfree[index - 1]
-            if self.data[index - 1].shape[1] - (amount + position) >= (
-                    -(-self.data[index - 2].shape[1] // 2) if
-                (index - 1) else 1):
-                self.data[index - 1][:, position:position + amount] = (
-                    self.data[index][:, :amount])
-                self.firstfree[index - 1] += amount
-                self.firstfree[index] = 0
-            else:
-                offset = self._randbit()
-                self.firstfree[index] = self._compact(
-                    self.data[index], amount, offset, self.data[index], 0,
-                    extremes=(index == 1))
-        return cap > 0
+    def _make_room(self) -> bool:
+        """Level 0 is full: ask the library what the sketch does now
+        (`milan_exemplar_sketch_plan_shift`: compactions up the levels, possibly a new
+        level 0) and carry the plan out on the level tensors.  False once the sketch
+        cannot grow any more (the sample rate halves)."""
+        n = len(self.data)
+        caps = (ctypes.c_int64 * n)(*[d.shape[1] for d in self.data])
+        fill = (ctypes.c_int64 * n)(*self.firstfree)
+        ops = (hip.SketchOp * (2 * n + 4))()
+        n_ops, n_out = ctypes.c_int(0), ctypes.c_int(0)
+        caps_out = (ctypes.c_int64 * (n + 1))()
+        fill_out = (ctypes.c_int64 * (n + 1))()
+        draw = hip.DRAW_BIT(self._draw)
+        hip._check(self.lib.milan_exemplar_sketch_plan_shift(
+            self.resolution, self.buffersize, int(self.samplerate >= 1.0), n, caps,
+            fill, draw, None, ops, len(ops), ctypes.byref(n_ops), caps_out, fill_out,
+            ctypes.byref(n_out)))
+        grown = True
+        for op in ops[:n_ops.value]:
+            if op.kind == hip.SKETCH_COMPACT:
+                self._compact(self.data[op.src], op.n, op.offset, self.data[op.dst],
+                              op.position, extremes=bool(op.extremes))
+            elif op.kind == hip.SKETCH_INSERT:
+                self.data.insert(0, torch.zeros(self.depth, op.capacity,
+                                                device=self.device))
+            elif op.kind == hip.SKETCH_MOVE:
+                self.data[op.dst][:, op.position:op.position + op.n] = (
+                    self.data[op.src][:, :op.n])
+            else:  # SKETCH_HALVE
+                self.samplerate *= 0.5
+                grown = False
+        self.firstfree = list(fill_out[:n_out.value])
+        assert [d.shape[1] for d in self.data] == list(caps_out[:n_out.value])
+        return grown
 
     def quantiles(self, quantile: float) -> torch.Tensor:
         """`quantiles(q)` for a scalar q -> (units,) float32 (:557-580)."""
@@ -495,7 +510,12 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
         else:
             pooled, samples = outputs
         if units is not None and units_dev is None:
-            units_dev = torch.tensor(units, dtype=torch.int32,
+            # the reference indexes `pooled[:, units]`: negative units count from
+            # the end, anything else out of range is an IndexError -- the kernels
+            # index `units[u]` unchecked, so this is decided here, on the host
+            channels = _as_hiddens(pooled).shape[1]
+            units_norm = _normalise_units(units, channels)
+            units_dev = torch.tensor(units_norm, dtype=torch.int32,
                                      device=pooled.device)
         topk.add_hiddens(pooled, units_dev)
         rq.add_hiddens(samples, units_dev)
@@ -529,7 +549,7 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
         todo = []
         for j in range(len(activations)):
             for unit, rank in needed[order[seen + j]]:
-                channel = unit if units is None else units[unit]
+                channel = unit if units is None else units_norm[unit]
                 todo += [j, channel, unit, rank]
         cells.render(lib, activations, images.to(activations.device), todo,
                      levels, mul, add)

@@ -22,6 +22,19 @@ GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _R
 PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
 PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16}
 FUSE_CHAIN = 1  # milan_set_fusion flag (include/milan_hip.h)
+SKETCH_COMPACT, SKETCH_INSERT, SKETCH_MOVE, SKETCH_HALVE = 0, 1, 2, 3
+
+
+class SketchOp(ctypes.Structure):
+    """`milan_sketch_op` (include/milan_hip.h)."""
+    _fields_ = [('kind', ctypes.c_int32), ('src', ctypes.c_int32),
+                ('dst', ctypes.c_int32), ('offset', ctypes.c_int32),
+                ('extremes', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('n', ctypes.c_int64), ('position', ctypes.c_int64),
+                ('capacity', ctypes.c_int64)]
+
+
+DRAW_BIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 # conv2d_nhwc test hook only: split_f16 with the LDS-strip 3x3 kernel forced
 _CONV_PRECISIONS = dict(PRECISIONS, split_f16_strip=2)
 DTYPE_U8, DTYPE_F32 = 0, 1
@@ -124,6 +137,10 @@ SIGNATURES = {
         (_I, [_P, _I, _I, _I, _P, _I, _I64, ctypes.POINTER(_I64),
               ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
               _I, _P, _I64, ctypes.POINTER(_I64), _P, _P, _SZ, _P]),
+    'milan_exemplar_sketch_plan_shift':
+        (_I, [_I64, _I64, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+              _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I64),
+              ctypes.POINTER(_I64), ctypes.POINTER(_I)]),
     'milan_exemplar_sketch_quantile':
         (_I, [ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
               _I, _I, _P, _F, _P, _P, _SZ, _P]),
@@ -317,8 +334,49 @@ class Context:
                                            beam, length))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None  # free before growing
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            try:
+                self._ws = torch.empty(need, dtype=torch.uint8,
+                                       device=self.device)
+            except torch.cuda.OutOfMemoryError as error:
+                free, total = torch.cuda.mem_get_info(self.device)
+                raise torch.cuda.OutOfMemoryError(
+                    f'the activation workspace for {neurons} neurons x {k} '
+                    f'exemplars needs {need / 2**30:.1f} GiB, {free / 2**30:.1f} '
+                    f'of {total / 2**30:.1f} GiB are free: lower '
+                    'Decoder.chunk_size (or use Context.fit_neurons)') from error
         return self._ws
+
+    def fit_neurons(self, neurons: int, k: int, image_size: int, beam: int,
+                    length: int, multiple: int = 16,
+                    headroom: float = 0.9) -> int:
+        """Largest neuron count <= `neurons` (a multiple of `multiple`) whose
+        workspace fits into `headroom` of the memory this process can still
+        get (free memory + what the current workspace already holds).  The
+        default chunk of 640 neurons takes 154 GB: fine on an idle 288 GB
+        MI355X, not when the GPU is shared."""
+        free, _ = torch.cuda.mem_get_info(self.device)
+        budget = headroom * (free + (self._ws.numel() if self._ws is not None
+                                     else 0))
+
+        def need(n):
+            return int(self.lib.milan_workspace_bytes(self._h, n, k, image_size,
+                                                      beam, length))
+
+        n = max(1, neurons)
+        if need(n) <= budget:
+            return n
+        lo, hi = 0, n  # need(lo) fits (or lo == 0), need(hi) does not
+        while hi - lo > multiple:
+            mid = (lo + hi) // 2 // multiple * multiple
+            if mid <= lo:
+                break
+            if need(mid) <= budget:
+                lo = mid
+            else:
+                hi = mid
+        if lo <= 0:
+            lo = min(multiple, n)
+        return lo
 
     # -- operators ----------------------------------------------------------
     def encode(self, images: torch.Tensor,

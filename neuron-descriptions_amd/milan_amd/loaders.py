@@ -74,20 +74,36 @@ def pretrained_sharded(config: str = 'base',
         model = pretrained(config, path=path, **kwargs)
         return model if device is None else model.to(device)
     rank = dist.get_rank()
-    box, state_dict = [None], None
+    # box = [payload, error]: a failure on the reading rank travels with the
+    # broadcast and is raised on EVERY rank (otherwise the others would wait in
+    # the collective forever)
+    box, state_dict = [None, None], None
     if rank == src:
-        kwargs.setdefault('map_location', 'cpu')
-        payload = serialize.load_payload(resolve(config, path), **kwargs)
-        state_dict = payload.pop('state_dict', None)
-        if state_dict is None:
-            raise ValueError('checkpoint has no state_dict')
-        box[0] = payload
+        try:
+            kwargs.setdefault('map_location', 'cpu')
+            payload = serialize.load_payload(resolve(config, path), **kwargs)
+            state_dict = payload.pop('state_dict', None)
+            if state_dict is None:
+                raise ValueError('checkpoint has no state_dict')
+            box[0] = payload
+        except Exception as error:  # noqa: BLE001 -- re-raised below, everywhere
+            box[1] = error
     dist.broadcast_object_list(box, src=src)
+    if box[1] is not None:
+        raise box[1]
     model = decoders.Decoder.deserialize(box[0]).eval()
     if device is not None:
         model = model.to(device)
     target = model.device
     shared = sharding.broadcast_state_dict(
         None if state_dict is None else dict(state_dict), target, src=src)
+    # the reference loads with strict=False (serialize.py:222-252); here the
+    # weights came over a collective, so a key lost on the way must not pass
+    # silently: the broadcast has to carry exactly the reading rank's keys
+    names = [sorted(state_dict)] if rank == src else [None]
+    dist.broadcast_object_list(names, src=src)
+    if sorted(shared) != names[0]:
+        raise RuntimeError('weight broadcast lost or added keys: '
+                           f'{sorted(set(names[0]) ^ set(shared))[:5]}')
     model.load_state_dict(shared, strict=False)
     return model

@@ -96,6 +96,17 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, device: torch.device) -> list:
+    """`value` of every rank, in rank order, on every rank (one tiny all_gather):
+    lets rank 0 report per-rank figures, so a straggler GPU shows in a scaling run."""
+    if not is_distributed():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]],
                          device: torch.device,
                          src: int = 0) -> Dict[str, torch.Tensor]:

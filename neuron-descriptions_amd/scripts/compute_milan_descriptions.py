@@ -18,7 +18,6 @@ from typing import List, Sequence, Tuple
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 
 import torch  # noqa: E402
-from torch.utils import data  # noqa: E402
 
 import milan_amd as milan  # noqa: E402
 from milan_amd import datasets as milannotations  # noqa: E402
@@ -59,9 +58,9 @@ def describe_shard(decoder, dataset, world: int, rank: int,
     predict_kwargs['batch_size'] = batch_size
     shard = dataset
     if world > 1:
-        shard = data.Subset(dataset, range(lo, hi))
-        # keep the memory-mapped uint8 fast path of `predict` for the block
-        shard.slice_uint8 = lambda a, b: dataset.slice_uint8(lo + a, lo + b)
+        # keeps the memory-mapped uint8 fast path of `predict` (incl. the one-pass
+        # `out=` fill of the pinned staging buffers) for the block
+        shard = milannotations.ShardView(dataset, lo, hi)
     mine = list(decoder.predict(shard, **predict_kwargs))
     if world == 1:
         return mine

@@ -274,3 +274,35 @@ def test_quantile_ties_keep_level_order(tmp_path):
     got = rq.quantiles(quantile).cpu()
     assert torch.equal(got, levels[True])
     assert int((levels[False] != levels[True]).sum()) <= 4
+
+
+def test_units_are_bounds_checked_like_the_reference(tmp_path):
+    """The reference selects `pooled[:, units]` (src/exemplars/compute.py:331-333):
+    a negative unit counts from the end, anything else out of range is an IndexError.
+    The kernels index `units[u]` unchecked, so the host side must decide this."""
+    hip.require_device('cuda')
+    model = synthetic.exemplar_model(8, 2, 5, relu=True)
+    dataset = data.TensorDataset(synthetic.exemplar_images(24, 16, 55))
+    tally, acts = cpu_model_callbacks(model, 'conv_2')
+    kwargs = dict(k=4, quantile=0.99, output_size=16, batch_size=8, image_size=16,
+                  num_workers=0, save_viz=False)
+    with pytest.raises(IndexError):
+        exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'a',
+                          units=[1, 8], **kwargs)
+    torch.manual_seed(0)
+    neg, _ = exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'b',
+                               units=[-1, 2], **kwargs)
+    torch.manual_seed(0)
+    pos, _ = exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'c',
+                               units=[2, 7], **kwargs)
+    # sorted([-1, 2]) = [-1, 2] -> channels (7, 2); sorted([2, 7]) -> (2, 7)
+    v_neg, i_neg = neg.result()
+    v_pos, i_pos = pos.result()
+    assert torch.equal(v_neg[0], v_pos[1]) and torch.equal(v_neg[1], v_pos[0])
+    assert torch.equal(i_neg[0], i_pos[1]) and torch.equal(i_neg[1], i_pos[0])
+    # the running statistics validate a caller-supplied unit tensor as well
+    topk = exemplars.RunningTopK(k=3)
+    hiddens = torch.rand(4, 8, 5, 5, device='cuda')
+    with pytest.raises(IndexError):
+        topk.add_hiddens(hiddens, torch.tensor([0, 9], dtype=torch.int32,
+                                               device='cuda'))

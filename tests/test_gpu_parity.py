@@ -452,8 +452,8 @@ STRIP_CASES = [c for c in CONV_CASES
 
 @pytest.mark.parametrize('case', STRIP_CASES)
 def test_lds_strip_conv3x3_kernel(dev, case):
-    """The 3x3 kernel with the input strip resident in LDS (off by default:
-    measured slower) stays correct: fp32-class error
+    """The 3x3 kernel with the input strip resident in LDS (a measured-and-rejected
+    experiment; compiled with `make EXPERIMENTS=1`) stays correct: fp32-class error
     against an fp64 reference, tiles spanning image borders, ragged tiles."""
     assert len(STRIP_CASES) >= 5
     n, h, w, cin, cout, k, stride, pad = case
@@ -465,7 +465,13 @@ def test_lds_strip_conv3x3_kernel(dev, case):
     x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
     got = {}
     for prec in ('split_f16', 'split_f16_strip'):
-        y = hip.conv2d_nhwc(x_nhwc, wt.to(dev), b.to(dev), 1, 1, precision=prec)
+        try:
+            y = hip.conv2d_nhwc(x_nhwc, wt.to(dev), b.to(dev), 1, 1, precision=prec)
+        except ValueError as error:
+            if 'experiments build' in str(error):
+                pytest.skip('the LDS-strip kernel is a rejected experiment: only in '
+                            'a `make EXPERIMENTS=1` build of the library')
+            raise
         got[prec] = y.permute(0, 3, 1, 2).cpu().double()
     scale = float(want.abs().max())
     err = {p: float((v - want).abs().max()) for p, v in got.items()}

@@ -393,6 +393,110 @@ def test_world_size_two_broadcast_and_gather_over_gloo(tmp_path):
     assert (tmp_path / 'ok1').read_text() == 'True'
 
 
+def _gloo_worker8(rank, world, port, tmp):
+    """World 8, shards aligned to 16: ragged last shard AND empty shards (VERDICT r2
+    item 6b).  Every neuron must come back exactly once, in order, on rank 0."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    r, w, _ = sharding.init_from_env(world, backend='gloo')
+    ok = True
+    for n in (100, 16, 7, 0, 1152):  # 100: ranks 0-5 x16, rank 6 x4, rank 7 empty
+        lo, hi = sharding.partition(n, w, r, align=16)
+        tokens = torch.arange(lo, hi).view(-1, 1).repeat(1, 15)
+        scores = torch.arange(lo, hi).float() * 0.5
+        t, s = sharding.gather_results(tokens, scores, dst=0)
+        if r == 0:
+            ok &= t.shape == (n, 15) and torch.equal(t[:, 3], torch.arange(n))
+            ok &= torch.equal(s, torch.arange(n).float() * 0.5)
+    sharding.finalize()
+    pathlib.Path(tmp, f'ok{rank}').write_text(str(bool(ok)))
+
+
+def test_world_size_eight_gather_with_ragged_and_empty_shards(tmp_path):
+    # the partition arithmetic at the BASELINE sizes (no data needed)
+    for n in (4096, 3904, 1152, 65536, 100, 7):
+        spans = [sharding.partition(n, 8, r, align=16) for r in range(8)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(b == c for (_, b), (c, _) in zip(spans, spans[1:]))
+        assert all(lo % 16 == 0 or lo == n for lo, _ in spans)
+        assert max(hi - lo for lo, hi in spans) <= -(-(-(-n // 8)) // 16) * 16
+    port = 29000 + (os.getpid() + 7) % 1000
+    mp.spawn(_gloo_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    for rank in range(8):
+        assert (tmp_path / f'ok{rank}').read_text() == 'True', rank
+
+
+def _sharded_load_worker(rank, world, port, tmp, path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sharding.init_from_env(world, backend='gloo')
+    from milan_amd import loaders
+    ok = True
+    # only rank 0 can see the file: the others must get skeleton + weights by broadcast
+    mine = path if rank == 0 else str(pathlib.Path(tmp, 'nowhere.pth'))
+    model = loaders.pretrained_sharded('base', path=mine)
+    want = torch.load(path, map_location='cpu')['state_dict']
+    got = model.state_dict()
+    ok &= all(torch.equal(got[k], v) for k, v in want.items())
+    ok &= tuple(model.indexer.vocab.tokens) == tuple(synthetic.vocab_tokens(12))
+    ok &= not model.training
+    # a failure on the reading rank is raised on EVERY rank (nobody hangs in the
+    # broadcast)
+    try:
+        loaders.pretrained_sharded('base', path=str(pathlib.Path(tmp, 'missing.pth')))
+        ok = False
+    except FileNotFoundError:
+        pass
+    sharding.finalize()
+    pathlib.Path(tmp, f'ok{rank}').write_text(str(bool(ok)))
+
+
+def test_pretrained_sharded_broadcasts_checkpoint_and_errors_over_gloo(tmp_path):
+    d = tiny_decoder()
+    path = tmp_path / 'milan-base.pth'
+    d.save(path)
+    port = 29000 + (os.getpid() + 13) % 1000
+    mp.spawn(_sharded_load_worker, args=(2, port, str(tmp_path), str(path)),
+             nprocs=2, join=True)
+    assert (tmp_path / 'ok0').read_text() == 'True'
+    assert (tmp_path / 'ok1').read_text() == 'True'
+
+
+def test_shard_view_keeps_the_fast_path_of_predict(tmp_path):
+    """One rank's block of a sharded run (scripts/compute_milan_descriptions.py):
+    same samples as the parent's [lo, hi), `slice_uint8(..., out=)` included, and the
+    attributes `Decoder.predict` checks before taking the uint8 path."""
+    import numpy
+    g = torch.Generator().manual_seed(5)
+    for layer, n_img in (('a', 5), ('b', 4)):
+        d = tmp_path / layer
+        d.mkdir()
+        numpy.save(d / 'images.npy', torch.randint(
+            0, 256, (n_img, 2, 3, 8, 8), dtype=torch.uint8, generator=g).numpy())
+        numpy.save(d / 'masks.npy', torch.randint(
+            0, 2, (n_img, 2, 1, 8, 8), dtype=torch.uint8, generator=g).numpy())
+    ds = datasets.TopImagesDataset(tmp_path)
+    view = datasets.ShardView(ds, 3, 8)
+    assert len(view) == 5 and view.unit(0) == ds.unit(3)
+    assert view.transform_images is None and view.device is None
+    assert torch.equal(view[1].images, ds[4].images) and view[-1].unit == ds[7].unit
+    im, mk = ds.slice_uint8(4, 7)
+    buf_i = torch.zeros(6, 2, 3, 8, 8, dtype=torch.uint8)
+    im2, mk2 = view.slice_uint8(1, 4, out=(buf_i, None))
+    assert torch.equal(im2, im) and torch.equal(mk2, mk)
+    assert im2.data_ptr() == buf_i.data_ptr()
+    import inspect
+    assert 'out' in inspect.signature(view.slice_uint8).parameters
+    ds.transform_images = lambda x: x
+    assert view.transform_images is ds.transform_images  # predict() then avoids it
+    with pytest.raises(IndexError):
+        view.slice_uint8(0, 6)
+    with pytest.raises(IndexError):
+        datasets.ShardView(ds, 3, 10)
+
+
 def test_exemplars_fail_loudly_without_gpu():
     """No CPU fallback in the exemplar computation either."""
     from milan_amd import exemplars
