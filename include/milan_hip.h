@@ -227,8 +227,10 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
  *                     bottleneck's 1x1 reduce conv run as one launch
  *                     (csrc/chain.hip; torchvision Bottleneck.forward as called from
  *                     src/milan/encoders.py:298).
- * Default: all on (environment MILAN_CHAIN=0 starts a context with it off). */
-enum { MILAN_FUSE_CHAIN = 1 };
+ * Default: MILAN_FUSE_CHAIN (environment MILAN_CHAIN=<flags> overrides at context
+ * creation). */
+enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
+       MILAN_FUSE_CHAIN_WIDE = 2 /* planes 256 (layer3): one wave per SIMD */ };
 int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);

@@ -1012,7 +1012,8 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       const float* identity = x;
       // Expand conv of this block + reduce conv of the next one in ONE launch: the
       // 4P-channel block output is written once and not read back by the next c1.
-      if (split && (c->fusion & MILAN_FUSE_CHAIN) && bi + 1 < blocks.size()) {
+      if (split && bi + 1 < blocks.size() &&
+          (c->fusion & (b.c3.cin >= 256 ? MILAN_FUSE_CHAIN_WIDE : MILAN_FUSE_CHAIN))) {
         const Bottleneck& nb = blocks[bi + 1];
         const int P = b.c3.cin;
         const bool shapes = !nb.basic && !nb.has_down && nb.c1.ws && b.c3.ws &&

@@ -633,7 +633,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_kernel(
 // bound by the HBM/L2 -> LDS DMA rate rather than by the matrix cores (MFMA-only
 // and DMA-only ablations each took ~half of the combined time): a 256x256 tile
 // moves 2/3 of the bytes per MFMA.  k-tile = 16 channel slots (one K=16 MFMA
-// slab, 64-byte LDS rows), 4-deep ring with three tiles in flight (128 KB LDS).
+// slab, 64-byte LDS rows), 5-deep ring with four tiles in flight (all 160 KB of LDS).
 // One accumulator set (the hl/lh cross terms are added into the main sum).
 // LDS row r holds 4 chunks [hi g0 | lo g0 | hi g1 | lo g1]; chunk p of row r
 // stores k-chunk p ^ ((r>>2)&3) (conflict-free for the DMA write and for the
@@ -659,7 +659,7 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   constexpr int LROWS = NT / 4;               // rows per loader pass
   constexpr int A_ITERS = BM / LROWS, B_ITERS = BN / LROWS;
   constexpr int LOADS = A_ITERS + B_ITERS;
-  static_assert(STAGES == 3 || STAGES == 4, "3- or 4-deep ring");
+  static_assert(STAGES >= 3 && STAGES <= 5, "3- to 5-deep ring");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                        // [STAGES][BM*16]
   float* Bs = smem + STAGES * BM * BK;     // [STAGES][BN*16]
@@ -1545,12 +1545,15 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     // (chunk size, world size).  Short M just leaves tile rows masked.
 #if MILAN_EXPERIMENTS
     if (g.tile_hint == 3) return launch_split16<256, 256, 4>(g, s);
+    if (g.tile_hint == 7) return launch_split16<256, 256, 5>(g, s);
     if (g.tile_hint == 4) return launch_split16<256, 128, 3>(g, s);
     if (g.tile_hint == 5) return launch_split16<128, 256, 3>(g, s);
     if (g.tile_hint == 1) return launch_cfg<256, 128, 3, true, true>(g, s);
     if (g.tile_hint == 2) return launch_cfg<128, 128, 2, true, true>(g, s);
 #endif
-    if (g.N % 256 == 0) return launch_split16<256, 256, 4>(g, s);
+    // 256x256 tile, 5-deep ring = all 160 KB of LDS, four k-tiles in flight (round 3,
+    // same-box A/B against the 4-deep ring: +0.5 % end to end, same bits)
+    if (g.N % 256 == 0) return launch_split16<256, 256, 5>(g, s);
     {
       // wide outputs that are not a multiple of 256 (the vocabulary GEMMs, N =
       // 5004): the 256-column tile when it pads no more than the 128-column one
@@ -1559,7 +1562,7 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
       const int pad256 = (g.N + 255) / 256 * 256 - g.N;
       const int pad128 = (g.N + 127) / 128 * 128 - g.N;
       if (g.N > 2048 && pad256 <= pad128)
-        return launch_split16<256, 256, 4>(g, s);
+        return launch_split16<256, 256, 5>(g, s);
     }
     return launch_split16<256, 128, 3>(g, s);
   }

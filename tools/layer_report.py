@@ -1,6 +1,9 @@
 """Per-layer GEMM throughput from a rocprofv3 rocpd database of bench.py.
 
-usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3] [fused_ds=0|1]
+usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3] [fused_ds=0|1] [chain=0|1]
+chain=1 (round 3): a bottleneck's expand conv c3 and the next bottleneck's reduce conv
+c1 are ONE launch (csrc/chain.hip) wherever the next block has no downsample branch and
+the stage is layer1..3; such pairs are reported as `lX.x.c3>c1`.
 Maps the igemm dispatches of one hot-path pass onto the ResNet-101 layer list
 (launch order is deterministic) and prints time / algorithmic TFLOP/s per
 layer group, then the decoder+LM GEMM total.
@@ -15,9 +18,11 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
     passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     fused = len(sys.argv) > 4 and sys.argv[4] == '1'  # split mode: ds folded into c3
+    chain = len(sys.argv) > 5 and sys.argv[5] == '1'
     rows = db.execute(
         "select name, start, end-start, grid_x from kernels where name like "
-        "'%igemm%' or name like '%conv3x3%' order by start").fetchall()
+        "'%igemm%' or name like '%conv3x3%' or name like '%chain_kernel%' "
+        "order by start").fetchall()
     per = len(rows) // passes
     rows = rows[per * (passes - 1):]
     layers = []
@@ -33,16 +38,30 @@ def main():
     h, inp = 56, 64
     for li, nb in enumerate((3, 4, 23, 3)):
         pl = 64 * 2**li
+        chained_c1 = False  # this block's c1 ran inside the previous block's launch
         for bi in range(nb):
             s = 2 if (bi == 0 and li > 0) else 1
-            conv(f'l{li+1}.{bi}.c1', h, inp, pl, 1, 1)
+            if not chained_c1:
+                conv(f'l{li+1}.{bi}.c1', h, inp, pl, 1, 1)
             h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
-            if bi == 0 and not fused:
-                conv(f'l{li+1}.{bi}.ds', h, inp, pl * 4, 1, s)
-            if bi == 0 and fused:
-                conv(f'l{li+1}.{bi}.c3+ds', h2, pl, pl * 4, 1, 1, extra_k=inp)
+            # chain.hip: planes <= 256, a next block in the stage; block 0 (two-source
+            # expand) only where its downsample has stride 1 (layer1)
+            chained_c1 = (chain and pl <= 256 and bi + 1 < nb and
+                          (bi > 0 or (fused and li == 0)))
+            tag = f'l{li+1}.{bi}.'
+            if chained_c1:
+                m = n * h2 * h2
+                k3 = pl + (inp if bi == 0 else 0)
+                name = tag + ('c3+ds>c1' if bi == 0 else 'c3>c1')
+                layers.append((name, m, pl * 4, k3 + pl,
+                               2 * m * pl * 4 * k3 + 2 * m * pl * pl * 4))
+            elif bi == 0 and not fused:
+                conv(tag + 'ds', h, inp, pl * 4, 1, s)
+                conv(tag + 'c3', h2, pl, pl * 4, 1, 1)
+            elif bi == 0:
+                conv(tag + 'c3+ds', h2, pl, pl * 4, 1, 1, extra_k=inp)
             else:
-                conv(f'l{li+1}.{bi}.c3', h2, pl, pl * 4, 1, 1)
+                conv(tag + 'c3', h2, pl, pl * 4, 1, 1)
             h, inp = h2, pl * 4
     agg, tot_t, tot_f = {}, 0, 0
     for (name, m, nn, k, fl), (_, _, du, _) in zip(layers, rows):
@@ -64,7 +83,8 @@ def main():
           sum(r[2] for r in dec) / 1e6)
     others = db.execute(
         "select name, count(*), sum(end-start) from kernels where name not "
-        "like '%igemm%' and name not like '%conv3x3%' group by name "
+        "like '%igemm%' and name not like '%conv3x3%' and name not like "
+        "'%chain_kernel%' group by name "
         "order by 3 desc limit 12").fetchall()
     for nm, c, t in others:
         print(f'  {nm[:60]:60s} x{c:5d} {t/1e6/passes:8.2f} ms/pass')
