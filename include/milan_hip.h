@@ -344,6 +344,13 @@ int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int
                               float* extremes, void* workspace,
                               size_t workspace_bytes, milan_stream stream);
 
+/* RunningQuantile._scan_extremes (runningstats.py:409-419), used by the sketch's
+ * subsampling regime where not every sample enters a buffer: column-wise minimum /
+ * maximum of `rows` [n_rows][n_units] (row-major, device) folded into `extremes`
+ * [n_units][2] = (min, max). */
+int milan_exemplar_rows_extremes(const float* rows, int64_t n_rows, int n_units,
+                                 float* extremes, milan_stream stream);
+
 /* What RunningQuantile does when level 0 is full and the bulk call above stopped: one
  * _shift() (runningstats.py:387-407) INCLUDING the _expand() it may end in
  * (:485-529), as a plan -- host arithmetic only, no device work.  The caller executes

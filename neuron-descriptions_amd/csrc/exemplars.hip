@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <mutex>
 #include <algorithm>
 
 #include <vector>
@@ -667,12 +668,20 @@ int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int
                 "sketch_add: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   if (n_ops) {
-    // the plan travels from a pinned staging buffer (a truly asynchronous copy);
-    // an event guards its reuse by the next call
-    static SketchOp* pinned = nullptr;
-    static size_t pinned_cap = 0;
-    static hipEvent_t pinned_free = nullptr;
-    static bool pinned_busy = false;
+    // the plan travels from a pinned staging buffer (a truly asynchronous copy); an
+    // event guards its reuse by the next call.  One buffer + event PER DEVICE (an event
+    // belongs to the device it was created on), under a lock
+    struct PlanStage { SketchOp* buf = nullptr; size_t cap = 0; hipEvent_t free = nullptr; bool busy = false; };
+    static std::map<int, PlanStage> stages;
+    static std::mutex stages_lock;
+    std::lock_guard<std::mutex> hold(stages_lock);
+    int device = 0;
+    MILAN_CHECK_HIP(hipGetDevice(&device));
+    PlanStage& st = stages[device];
+    SketchOp*& pinned = st.buf;
+    size_t& pinned_cap = st.cap;
+    hipEvent_t& pinned_free = st.free;
+    bool& pinned_busy = st.busy;
     if (!pinned_free) MILAN_CHECK_HIP(hipEventCreateWithFlags(&pinned_free, hipEventDisableTiming));
     if (pinned_busy) { MILAN_CHECK_HIP(hipEventSynchronize(pinned_free)); pinned_busy = false; }
     if (pinned_cap < n_ops) {
@@ -752,6 +761,44 @@ int milan_exemplar_sketch_add(const float* hiddens, int batch, int channels, int
   for (int l = 0; l < n_levels; ++l) firstfree[l] = ff[l];
   *currentbit = bit;
   *consumed = index;
+  return 0;
+}
+
+// min / max over the rows of a (rows, units) matrix, 64 units per workgroup: lanes walk
+// the columns (coalesced), the four waves walk the rows, LDS combines them
+__global__ __launch_bounds__(256) void rows_extremes_kernel(
+    const float* __restrict__ rows, long n_rows, int n_units, float* __restrict__ extremes) {
+  __shared__ float lo[4][64], hi[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 64 + lane;
+  float mn = INFINITY, mx = -INFINITY;
+  if (unit < n_units)
+    for (long r = wave; r < n_rows; r += 4) {
+      const float v = rows[r * n_units + unit];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+  lo[wave][lane] = mn;
+  hi[wave][lane] = mx;
+  __syncthreads();
+  if (wave == 0 && unit < n_units) {
+    for (int w = 1; w < 4; ++w) {
+      mn = fminf(mn, lo[w][lane]);
+      mx = fmaxf(mx, hi[w][lane]);
+    }
+    extremes[2 * unit] = fminf(extremes[2 * unit], mn);
+    extremes[2 * unit + 1] = fmaxf(extremes[2 * unit + 1], mx);
+  }
+}
+
+int milan_exemplar_rows_extremes(const float* rows, int64_t n_rows, int n_units,
+                                 float* extremes, milan_stream stream) {
+  MILAN_REQUIRE(rows && extremes, MILAN_ERR_ARG, "rows_extremes: null argument");
+  MILAN_REQUIRE(n_rows >= 0 && n_units > 0, MILAN_ERR_SHAPE, "rows_extremes: bad sizes");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(rows_extremes_kernel, dim3((n_units + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, rows, (long)n_rows, n_units, extremes);
+  MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }
 

@@ -154,6 +154,39 @@ class RunningTopK:
     def to_(self, device) -> None:  # results are read with .result().cpu()
         pass
 
+    # -- persistence: field names of netdissect's RunningTopK (runningstats.py:118-149)
+    def state_dict(self) -> Dict[str, Any]:
+        values, index = self.result()
+        units, filled = values.shape
+        return dict(constructor=f'{__name__}.RunningTopK()', k=self.k,
+                    count=self.count, largest=True, data_shape=(units,),
+                    top_data=values.cpu().numpy(), top_index=index.cpu().numpy(),
+                    next=filled,
+                    linear_index=numpy.arange(units, dtype=numpy.int64) * filled,
+                    perm=None)
+
+    def set_state_dict(self, dic) -> None:
+        self.k = int(dic['k'])
+        self.count = int(dic['count'])
+        width = int(dic['next'])
+        data = torch.from_numpy(numpy.asarray(dic['top_data']))[:, :width]
+        index = torch.from_numpy(numpy.asarray(dic['top_index']))
+        # upstream keeps an unsorted buffer of up to 5k candidates per unit: its
+        # `result()` is a top-k over it (value descending), read back through the
+        # flat `linear_index` offsets
+        keep = min(self.k, width)
+        values, where = data.float().topk(keep, dim=1, sorted=True)
+        linear = torch.from_numpy(numpy.asarray(dic['linear_index'])).view(-1, 1)
+        picked = index.reshape(-1)[(where + linear).reshape(-1)].view_as(where)
+        device = self.device or hip.require_device('cuda')
+        self.device = device
+        self.values = torch.zeros(data.shape[0], self.k, device=device)
+        self.index = torch.zeros(data.shape[0], self.k, dtype=torch.long,
+                                 device=device)
+        self.values[:, :keep] = values.to(device)
+        self.index[:, :keep] = picked.long().to(device)
+        self.filled = keep
+
 
 # ---------------------------------------------------------------------------
 # RunningQuantile (src/deps/netdissect/runningstats.py:274-627)
@@ -229,9 +262,16 @@ class RunningQuantile:
         self.count += supplied
         self.batchcount += 1
         if self.samplerate < 1.0:
-            raise NotImplementedError(
-                'RunningQuantile subsampling regime (reached after ~1e10 '
-                'samples per unit) is not built')
+            # subsampling regime (runningstats.py:359-367): every item still counts
+            # for the extremes, a Bernoulli(samplerate) portion of each chunk enters
+            rows = self._rows(hiddens, units)
+            self._scan_extremes(rows)
+            chunk = int(math.ceil(self.buffersize / self.samplerate))
+            for lo in range(0, len(rows), chunk):
+                sample = self._sample_portion(rows[lo:lo + chunk])
+                if len(sample):
+                    self._add_rows(sample)
+            return
         index = 0
         while index < supplied:  # runningstats.py:363-385
             if self.bulk and max(d.shape[1] for d in self.data) <= 8192:
@@ -239,14 +279,17 @@ class RunningQuantile:
                                         index)
                 if index >= supplied:
                     break
-                # level 0 is full and the next _shift() needs _expand() or a
-                # refill of the random bits: that one goes the per-op way
+                # level 0 is full and the next step needs a new level or a refill
+                # of the random bits: that one goes the per-operation way
             ff = self.firstfree[0]
             available = self.data[0].shape[1] - ff
             if available == 0:
                 if not self._make_room():
-                    raise NotImplementedError(
-                        'RunningQuantile subsampling regime is not built')
+                    # no further level: the rate has just halved; the rest of this
+                    # batch goes through the subsampling path
+                    self._add_rows(self._rows(hiddens, units)[index:],
+                                   rate_just_halved=True)
+                    return
                 ff = self.firstfree[0]
                 available = self.data[0].shape[1] - ff
             copycount = min(available, supplied - index)
@@ -257,6 +300,62 @@ class RunningQuantile:
                     self.data[0].shape[1], ff, _stream(self.device)))
             self.firstfree[0] += copycount
             index += copycount
+
+    # -- subsampling regime (rows = samples x units matrices on the device) ----------
+    @staticmethod
+    def _rows(hiddens: torch.Tensor, units: Optional[torch.Tensor]) -> torch.Tensor:
+        """(batch, channels, *spatial) -> (samples, units), row order (image, y, x)
+        like compute.py:329-330; a gather + copy, no arithmetic."""
+        if units is not None:
+            hiddens = hiddens.index_select(1, units.long())
+        if hiddens.dim() == 2:
+            return hiddens.contiguous()
+        channels = hiddens.shape[1]
+        return hiddens.reshape(hiddens.shape[0], channels, -1).permute(
+            0, 2, 1).reshape(-1, channels).contiguous()
+
+    def _scan_extremes(self, rows: torch.Tensor) -> None:
+        with torch.cuda.device(self.device):
+            hip._check(self.lib.milan_exemplar_rows_extremes(
+                rows.data_ptr(), len(rows), self.depth, self.extremes.data_ptr(),
+                _stream(self.device)))
+
+    def _sample_portion(self, rows: torch.Tensor) -> torch.Tensor:
+        """runningstats.py:1221-1224.  The coin flips come from torch's global CPU
+        generator, like a reference run on CPU tensors, so seeded runs agree."""
+        bits = torch.bernoulli(torch.zeros(len(rows), dtype=torch.uint8),
+                               self.samplerate)
+        return rows[bits.bool().to(rows.device)]
+
+    def _add_rows(self, rows: torch.Tensor, rate_just_halved: bool = False) -> None:
+        """`_add_every` for a (samples, units) matrix, one append per free stretch
+        of level 0; when the sketch cannot grow, the remainder is thinned out."""
+        def thin(rest):
+            if self.samplerate >= 0.5:  # first time: the source is very large
+                self._scan_extremes(rest)
+            return self._sample_portion(rest)
+
+        if rate_just_halved:
+            rows = thin(rows)
+        index, supplied = 0, len(rows)
+        while index < supplied:
+            room = self.data[0].shape[1] - self.firstfree[0]
+            if room == 0:
+                if not self._make_room():
+                    rows = thin(rows[index:])
+                    index, supplied = 0, len(rows)
+                    if supplied == 0:
+                        break
+                room = self.data[0].shape[1] - self.firstfree[0]
+            take = min(room, supplied - index)
+            rows = rows.contiguous()
+            with torch.cuda.device(self.device):
+                hip._check(self.lib.milan_exemplar_sketch_append(
+                    rows.data_ptr(), supplied, self.depth, 1, None, self.depth,
+                    index, take, self.data[0].data_ptr(), self.data[0].shape[1],
+                    self.firstfree[0], _stream(self.device)))
+            self.firstfree[0] += take
+            index += take
 
     def _add_bulk(self, hiddens, batch, channels, hw, units, first) -> int:
         """As many of the remaining samples as the state machine can take
@@ -354,6 +453,44 @@ class RunningQuantile:
                 _stream(self.device)))
         return out
 
+    # -- persistence: netdissect's format (runningstats.py:428-471) ------------------
+    def state_dict(self) -> Dict[str, Any]:
+        levels = [d[:, :f].t().cpu().numpy()
+                  for d, f in zip(self.data or [], self.firstfree)]
+        packed = numpy.empty(len(levels) + 1, dtype=object)  # trailing None as upstream
+        for i, level in enumerate(levels):
+            packed[i] = level
+        return dict(constructor=f'{__name__}.RunningQuantile()',
+                    resolution=self.resolution, depth=self.depth,
+                    buffersize=self.buffersize, samplerate=self.samplerate,
+                    data=packed, sizes=[d.shape[1] for d in self.data or []],
+                    extremes=self.extremes.cpu().numpy(), size=self.count,
+                    batchcount=self.batchcount)
+
+    def set_state_dict(self, dic) -> None:
+        self.resolution = int(dic['resolution'])
+        self.randbits = torch.ByteTensor(self.resolution)
+        self.currentbit = len(self.randbits) - 1
+        depth = int(dic['depth'])
+        self.buffersize = int(dic['buffersize'])
+        samplerate = float(dic['samplerate'])
+        device = self.device or hip.require_device('cuda')
+        self._lazy_init(depth, device)
+        self.samplerate = samplerate
+        self.data, self.firstfree = [], []
+        for level, size in zip(dic['data'], dic['sizes']):
+            if level is None:
+                continue
+            level = numpy.asarray(level, dtype=numpy.float32)  # (filled, depth)
+            buf = torch.zeros(depth, int(size), device=device)
+            buf[:, :level.shape[0]] = torch.from_numpy(level).t().to(device)
+            self.data.append(buf)
+            self.firstfree.append(int(level.shape[0]))
+        self.extremes = torch.from_numpy(
+            numpy.asarray(dic['extremes'], dtype=numpy.float32)).to(device).contiguous()
+        self.count = int(dic['size'])
+        self.batchcount = int(dic['batchcount']) if 'batchcount' in dic else 0
+
     def to_(self, device) -> None:
         pass
 
@@ -431,6 +568,37 @@ class _Cells:
 ActivationStats = Tuple[RunningTopK, RunningQuantile]
 
 
+def _pull_prefix(prefix: str, state) -> Dict[str, Any]:
+    head = prefix + '.'
+    return {key[len(head):]: state[key] for key in state if key.startswith(head)}
+
+
+def _load_cache(path: Optional[pathlib.Path], args: Dict[str, Any]):
+    """netdissect's `load_cached_state` (tally.py:741-756): the file counts only if
+    every recorded argument equals the current one."""
+    if path is None or not path.exists():
+        return None
+    try:
+        state = dict(numpy.load(path, allow_pickle=True))
+    except Exception:  # noqa: BLE001 -- an unreadable cache is a missing cache
+        return None
+    for key, value in args.items():
+        if key not in state:
+            return None
+        have = state[key]
+        have = have.item() if getattr(have, 'shape', None) == () else have
+        if have != value:
+            return None
+    return state
+
+
+def _save_cache(path: pathlib.Path, state: Dict[str, Any],
+                args: Dict[str, Any]) -> None:
+    path.parent.mkdir(exist_ok=True, parents=True)
+    with open(path, 'wb') as handle:  # (numpy.savez appends .npz to bare names)
+        numpy.savez(handle, **state, **args)
+
+
 def compute(compute_topk_and_quantile: Callable[..., Any],
             compute_activations: Callable[..., Any],
             dataset: data.Dataset,
@@ -459,8 +627,12 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
     (pooled (batch, units), activations (samples, units)) or -- cheaper, no
     permuted copy -- the hidden tensor (batch, units, h, w) itself;
     `compute_activations(*batch)` returns hiddens (batch, units, h, w) or
-    (hiddens, images).  The netdissect caches (`*_cache_file`) are accepted and
-    ignored: the tally is not the slow part here.
+    (hiddens, images).  `tally_cache_file` / `masks_cache_file` work as upstream
+    (compute.py:140-146, tally.py:199-222,741-767): the first pass's statistics and
+    the second pass's arrays are written there and a later call with the same
+    arguments loads them instead of touching the dataset; `clear_cache_files`
+    deletes them first.  The tally file uses netdissect's key layout (`rtk.*`,
+    `rq.*`, `sample_size`, `k`, `r`).
     """
     if units is not None and not units:
         raise ValueError('when setting `units`, must provide >= 1 unit')
@@ -472,9 +644,15 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
     if image_size is None and not hasattr(dataset, 'transform'):
         raise ValueError('dataset has no `transform` property so '
                          'image_size= must be set')
-    del tally_cache_file, masks_cache_file, clear_cache_files
     del display_progress, image_size
     lib = hip.load_library()
+    caches = [pathlib.Path(f) if f is not None else None
+              for f in (tally_cache_file, masks_cache_file)]
+    if clear_cache_files:
+        for cache in caches:
+            if cache is not None and cache.exists():
+                cache.unlink()
+    tally_cache, masks_cache = caches
 
     if results_dir is None:
         import os
@@ -500,9 +678,14 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
 
     # ---- pass 1: tally (tally.tally_topk_and_quantile, tally.py:199-222) ----
     topk, rq = RunningTopK(k=k), RunningQuantile(r=4096)
+    tally_args = dict(sample_size=None, k=k, r=4096)
+    cached = _load_cache(tally_cache, tally_args)
+    if cached is not None:
+        topk.set_state_dict(_pull_prefix('rtk', cached))
+        rq.set_state_dict(_pull_prefix('rq', cached))
     loader = data.DataLoader(dataset, batch_size=batch_size,
                              num_workers=num_workers)
-    for batch in loader:
+    for batch in (loader if cached is None else ()):
         batch = batch if isinstance(batch, (list, tuple)) else [batch]
         outputs = compute_topk_and_quantile(*batch)
         if isinstance(outputs, torch.Tensor):
@@ -520,7 +703,14 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
         topk.add_hiddens(pooled, units_dev)
         rq.add_hiddens(samples, units_dev)
 
-    if not (save_results or save_viz):
+    if cached is None and tally_cache is not None:
+        state = {f'rtk.{key}': v for key, v in topk.state_dict().items()}
+        state.update({f'rq.{key}': v for key, v in rq.state_dict().items()})
+        _save_cache(tally_cache, state, tally_args)
+    if units is not None and units_dev is None:  # tally came from the cache
+        units_norm = None
+
+    if not (save_results or save_viz or masks_cache is not None):
         return topk, rq
 
     # ---- pass 2: render the top images (imgviz.py / tally.gather_topk) --------
@@ -536,10 +726,16 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
         for rank, imgnum in enumerate(ids_host[unit].tolist()):
             needed.setdefault(imgnum, []).append((unit, rank))
     order = sorted(needed)
+    masks_args = dict(k=k, quantile=quantile, output_size=output_size,
+                      n_units=n_units)
+    rendered = _load_cache(masks_cache, masks_args)
+    if rendered is not None:
+        for name in ('images', 'masks', 'masked'):
+            getattr(cells, name).copy_(torch.from_numpy(rendered[name]))
     loader = data.DataLoader(dataset, sampler=order, batch_size=batch_size,
                              num_workers=num_workers)
     seen = 0
-    for batch in loader:
+    for batch in (loader if rendered is None else ()):
         batch = batch if isinstance(batch, (list, tuple)) else [batch]
         outputs = compute_activations(*batch)
         if isinstance(outputs, torch.Tensor):
@@ -549,12 +745,18 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
         todo = []
         for j in range(len(activations)):
             for unit, rank in needed[order[seen + j]]:
+                if units is not None and units_norm is None:
+                    units_norm = _normalise_units(units, activations.shape[1])
                 channel = unit if units is None else units_norm[unit]
                 todo += [j, channel, unit, rank]
         cells.render(lib, activations, images.to(activations.device), todo,
                      levels, mul, add)
         seen += len(activations)
 
+    if rendered is None and masks_cache is not None:
+        _save_cache(masks_cache,
+                    {name: getattr(cells, name).cpu().numpy()
+                     for name in ('images', 'masks', 'masked')}, masks_args)
     if save_results:
         numpy.save(f'{results_dir}/images.npy', cells.images.cpu().numpy())
         numpy.save(f'{results_dir}/masks.npy', cells.masks.cpu().numpy())

@@ -137,6 +137,7 @@ SIGNATURES = {
         (_I, [_P, _I, _I, _I, _P, _I, _I64, ctypes.POINTER(_I64),
               ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
               _I, _P, _I64, ctypes.POINTER(_I64), _P, _P, _SZ, _P]),
+    'milan_exemplar_rows_extremes': (_I, [_P, _I64, _I, _P, _P]),
     'milan_exemplar_sketch_plan_shift':
         (_I, [_I64, _I64, _I, _I, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
               _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I64),

@@ -90,10 +90,25 @@ class QuantileSketch:
             self.extremes[:, 1] = -float('inf')
         assert incoming.shape[1] == self.depth
         self.count += incoming.shape[0]
-        if self.samplerate < 1.0:
-            raise NotImplementedError(
-                'subsampling regime (> ~1e10 samples) is not restated')
-        self._add_every(incoming)
+        if self.samplerate >= 1.0:
+            self._add_every(incoming)
+            return
+        # subsampling regime (runningstats.py:359-367): every item still counts for
+        # the extremes; a Bernoulli(samplerate) portion of each chunk enters the sketch
+        self._scan_extremes(incoming)
+        chunksize = int(math.ceil(self.buffersize / self.samplerate))
+        for index in range(0, len(incoming), chunksize):
+            sample = self._sample_portion(incoming[index:index + chunksize])
+            if len(sample):
+                self._add_every(sample)
+
+    def _scan_extremes(self, incoming: torch.Tensor) -> None:  # :409-413
+        self._update_extremes(incoming.min(dim=0)[0], incoming.max(dim=0)[0])
+
+    def _sample_portion(self, vec: torch.Tensor) -> torch.Tensor:  # :1221-1224
+        bits = torch.bernoulli(torch.zeros(vec.shape[0], dtype=torch.uint8),
+                               self.samplerate)  # torch's GLOBAL (CPU) generator
+        return vec[bits.bool()]
 
     def _add_every(self, incoming: torch.Tensor) -> None:
         supplied, index = len(incoming), 0
@@ -102,7 +117,12 @@ class QuantileSketch:
             available = self.data[0].shape[1] - ff
             if available == 0:
                 if not self._shift():
-                    raise NotImplementedError('subsampling regime')
+                    # no room for another level: the rate halved (:376-383)
+                    incoming = incoming[index:]
+                    if self.samplerate >= 0.5:
+                        self._scan_extremes(incoming)
+                    incoming = self._sample_portion(incoming)
+                    index, supplied = 0, len(incoming)
                 ff = self.firstfree[0]
                 available = self.data[0].shape[1] - ff
             copycount = min(available, supplied - index)

@@ -306,3 +306,123 @@ def test_units_are_bounds_checked_like_the_reference(tmp_path):
     with pytest.raises(IndexError):
         topk.add_hiddens(hiddens, torch.tensor([0, 9], dtype=torch.int32,
                                                device='cuda'))
+
+
+# ---------------------------------------------------------------------------
+# G16 / G17: the sketch's subsampling regime, state dicts, cache files
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def S():
+    return (torch.load(GOLDEN_DIR / 'reference_goldens_sketch.pt'),
+            json.loads((GOLDEN_DIR / 'reference_goldens_sketch.json').read_text()))
+
+
+def _sketch_batches(case):
+    g = torch.Generator().manual_seed(case['data_seed'])
+    for _ in range(case['batches']):
+        yield torch.randn(case['rows'], case['units'], generator=g) * 3 + 1
+
+
+@pytest.mark.parametrize('name', ['tiny_r', 'tiny_r_wide'])
+def test_sketch_subsampling_regime_matches_reference(S, name):
+    """netdissect's RunningQuantile with a tiny r reaches `samplerate < 1` after a few
+    hundred samples (runningstats.py:343-385): the HIP sketch must follow it state for
+    state -- same level fills after every batch, same quantiles, bit for bit (seeded:
+    both draw the compaction bits and the Bernoulli masks from torch's global RNG)."""
+    hip.require_device('cuda')
+    tensors, meta = S
+    case = meta[name]
+    sketch = exemplars.RunningQuantile(r=case['r'])
+    torch.manual_seed(case['rng'])
+    for i, batch in enumerate(_sketch_batches(case)):
+        sketch.add(batch.cuda())
+        rate, levels, held = case['trajectory'][i]
+        assert (sketch.samplerate, len(sketch.data), sum(sketch.firstfree)) == \
+            (rate, levels, held), i
+    assert sketch.samplerate == case['samplerate'] < 1.0
+    assert sketch.count == case['count']
+    got = torch.stack([sketch.quantiles(q).cpu() for q in (0.05, 0.5, 0.95)])
+    assert torch.equal(got, tensors[f'{name}_quantiles'])
+
+
+def test_reference_state_dicts_load(S):
+    """What the reference's tally cache holds (`state_dict()` of both running
+    statistics, runningstats.py:118-149,428-471) loads here and answers alike; and our
+    own state dicts round-trip."""
+    hip.require_device('cuda')
+    tensors, meta = S
+    case = meta['tiny_r']
+    levels = [tensors[f'tiny_r_state_level{i}'].numpy()
+              for i in range(len(case['state']['sizes']))]
+    state = dict(case['state'], data=levels + [None],
+                 extremes=tensors['tiny_r_extremes'].numpy())
+    rq = exemplars.RunningQuantile()
+    rq.set_state_dict(state)
+    got = torch.stack([rq.quantiles(q).cpu() for q in (0.05, 0.5, 0.95)])
+    assert torch.equal(got, tensors['tiny_r_quantiles'])
+    again = exemplars.RunningQuantile()
+    again.set_state_dict(rq.state_dict())
+    assert torch.equal(again.quantiles(0.5).cpu(), tensors['tiny_r_quantiles'][1])
+    assert again.count == case['count'] and again.samplerate == case['samplerate']
+    t = meta['topk']
+    topk = exemplars.RunningTopK(k=t['k'])
+    topk.set_state_dict(dict(k=t['k'], count=t['count'], next=t['next'],
+                             top_data=tensors['topk_state_top_data'].numpy(),
+                             top_index=tensors['topk_state_top_index'].numpy(),
+                             linear_index=tensors['topk_state_linear_index'].numpy()))
+    values, index = topk.result()
+    assert torch.equal(values.cpu(), tensors['topk_values'])
+    assert torch.equal(index.cpu(), tensors['topk_index'])
+    twin = exemplars.RunningTopK(k=t['k'])
+    twin.set_state_dict(topk.state_dict())
+    assert torch.equal(twin.result()[1].cpu(), tensors['topk_index'])
+
+
+def test_cache_files_replace_the_passes_over_the_dataset(tmp_path):
+    """compute.py:140-146 / tally.py:199-222: with `tally_cache_file` and
+    `masks_cache_file` in place a second call must not read the dataset at all, and
+    `clear_cache_files` makes it read again."""
+    hip.require_device('cuda')
+
+    class Counting(data.Dataset):
+        def __init__(self, images):
+            self.images, self.reads = images, 0
+
+        def __len__(self):
+            return len(self.images)
+
+        def __getitem__(self, i):
+            self.reads += 1
+            return (self.images[i],)
+
+    model = synthetic.exemplar_model(6, 2, 4, relu=True)
+    dataset = Counting(synthetic.exemplar_images(40, 16, 77))
+    tally, acts = cpu_model_callbacks(model, 'conv_2')
+    kwargs = dict(k=5, quantile=0.9, output_size=16, batch_size=16, image_size=16,
+                  num_workers=0, save_viz=False,
+                  tally_cache_file=tmp_path / 'cache' / 'tally.npz',
+                  masks_cache_file=tmp_path / 'cache' / 'masks.npz')
+    first, rq1 = exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'a',
+                                   **kwargs)
+    reads = dataset.reads
+    assert reads >= 40 and (tmp_path / 'cache' / 'tally.npz').exists()
+    second, rq2 = exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'b',
+                                    **kwargs)
+    assert dataset.reads == reads, 'the cached call went back to the dataset'
+    assert torch.equal(first.result()[1], second.result()[1])
+    assert torch.equal(rq1.quantiles(0.9), rq2.quantiles(0.9))
+    for name in ('images', 'masks'):
+        a = numpy.load(tmp_path / 'a' / f'{name}.npy')
+        b = numpy.load(tmp_path / 'b' / f'{name}.npy')
+        assert (a == b).all()
+    # the tally file follows netdissect's key layout
+    keys = set(numpy.load(tmp_path / 'cache' / 'tally.npz', allow_pickle=True).keys())
+    assert {'rtk.top_data', 'rq.data', 'rq.sizes', 'k', 'r', 'sample_size'} <= keys
+    # a different k invalidates the cache; clear_cache_files removes it
+    exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'c',
+                      **dict(kwargs, k=4))
+    assert dataset.reads > reads
+    reads = dataset.reads
+    exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'd',
+                      clear_cache_files=True, **kwargs)
+    assert dataset.reads > reads

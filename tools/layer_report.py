@@ -18,7 +18,8 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
     passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     fused = len(sys.argv) > 4 and sys.argv[4] == '1'  # split mode: ds folded into c3
-    chain = len(sys.argv) > 5 and sys.argv[5] == '1'
+    chain = len(sys.argv) > 5 and sys.argv[5] in ("1", "2")
+    wide = len(sys.argv) > 5 and sys.argv[5] == "2"  # layer3 chains on too
     rows = db.execute(
         "select name, start, end-start, grid_x from kernels where name like "
         "'%igemm%' or name like '%conv3x3%' or name like '%chain_kernel%' "
@@ -46,7 +47,7 @@ def main():
             h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
             # chain.hip: planes <= 256, a next block in the stage; block 0 (two-source
             # expand) only where its downsample has stride 1 (layer1)
-            chained_c1 = (chain and pl <= 256 and bi + 1 < nb and
+            chained_c1 = (chain and pl <= (256 if wide else 128) and bi + 1 < nb and
                           (bi > 0 or (fused and li == 0)))
             tag = f'l{li+1}.{bi}.'
             if chained_c1:
