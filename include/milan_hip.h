@@ -227,10 +227,15 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
  *                     bottleneck's 1x1 reduce conv run as one launch
  *                     (csrc/chain.hip; torchvision Bottleneck.forward as called from
  *                     src/milan/encoders.py:298).
- * Default: MILAN_FUSE_CHAIN (environment MILAN_CHAIN=<flags> overrides at context
- * creation). */
+ *   MILAN_FUSE_STEM   conv1 7x7/2 + bn1 + ReLU + maxpool 3x3/2 as one persistent
+ *                     launch over LDS-resident input tiles (csrc/stem.hip; the raw
+ *                     conv1 tensor, pyramid level 0 of encoders.py:303-320, is only
+ *                     materialised where the mask-weighted pooling reads it).
+ * Default: MILAN_FUSE_CHAIN | MILAN_FUSE_STEM (environment MILAN_CHAIN=<flags>
+ * overrides at context creation). */
 enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
-       MILAN_FUSE_CHAIN_WIDE = 2 /* planes 256 (layer3): one wave per SIMD */ };
+       MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): one wave per SIMD */
+       MILAN_FUSE_STEM = 4 };
 int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);

@@ -137,6 +137,24 @@ struct ChainArgs {
 };
 bool chain_supported(int P, int KD);
 int launch_chain(const ChainArgs& a, hipStream_t s);
+// ---- fused split-f16 stem (stem.hip): conv1 7x7/2 + bn1 + ReLU + maxpool 3x3/2 ----
+struct StemArgs {
+  const float* in;      // pixel-pair groups [n][H][G][hi x8 | lo x8] (encoder.hip)
+  const float* ws;      // split weights [64][224] (pack_stem_pairs), scaled
+  const float* bias;    // [64] or nullptr
+  float acc_scale;      // 1 / weight scale
+  const float* scale;   // bn1 folded: y = x * scale + shift
+  const float* shift;
+  float* raw;           // [n][h1][w1][64] fp32 conv1 output (pyramid level 0) or nullptr
+  float* y;             // [n][hp][wp][64] split format
+  const int* bbox;      // [n][4] = y0, y1, x0, x1 (inclusive) of the conv1 pixels the
+                        // level-0 pooling reads, or nullptr = write every raw pixel
+  const float* zero;    // >= 64 B of zeros
+  int n, H, G, h1, w1, hp, wp;
+  int tiles_y, tiles_x;  // filled by the launcher
+};
+bool stem_fused_supported(int cout, int Kp);
+int launch_stem_fused(const StemArgs& a, hipStream_t s);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, long long* launches);
 int profile_read_stages(double* table /* [MILAN_STAGE_COUNT][6] */);
@@ -247,7 +265,7 @@ struct milan_ctx {
   milan_dims d{};
   bool finalized = false;
   int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16
-  int fusion = MILAN_FUSE_CHAIN;  // milan_set_fusion
+  int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_STEM;  // milan_set_fusion
   // hipGraph cache of whole decode passes (milan_set_graph_capture)
   int graph_capture = 0;
   struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int seen = 0; };

@@ -559,7 +559,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void mask_pyramid_kernel(
     const T* __restrict__ masks, int H, int W, Levels lv,
     int* __restrict__ list_idx, float* __restrict__ list_w,
-    int* __restrict__ list_n) {
+    int* __restrict__ list_n, int* __restrict__ bbox = nullptr) {
   // every product/sum below is rounded as written (ATen's scalar formula), the
   // same for the uint8 and float instantiations
 #pragma clang fp contract(off)
@@ -608,11 +608,19 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
   if (threadIdx.x < 64) {
     const long base = (long)img * lv.per_image + lv.off[l];
     int count = 0;
+    // level 0 only: bounding box (rows y0..y1, columns x0..x1) of the listed pixels,
+    // i.e. of everything the pooling of the raw conv1 tensor reads (stem.hip)
+    int by0 = 0x7fffffff, by1 = -1, bx0 = 0x7fffffff, bx1 = -1;
     for (int p0 = 0; p0 < P; p0 += 64) {
       const int p = p0 + threadIdx.x;
       float v = p < P ? weight(p) : 0.f;
       if (valid) v = v / total;
       const bool nz = (p < P) && (v != 0.f);
+      if (nz && l == 0) {
+        const int oy = p / w, ox = p - oy * w;
+        by0 = min(by0, oy); by1 = max(by1, oy);
+        bx0 = min(bx0, ox); bx1 = max(bx1, ox);
+      }
       const unsigned long long mask = __ballot(nz);
       const int pos =
           count + __popcll(mask & ((1ull << threadIdx.x) - 1ull));
@@ -623,6 +631,16 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
       count += __popcll(mask);
     }
     if (threadIdx.x == 0) list_n[img * 5 + l] = count;
+    if (l == 0 && bbox != nullptr) {
+      for (int o = 32; o > 0; o >>= 1) {
+        by0 = min(by0, __shfl_xor(by0, o)); by1 = max(by1, __shfl_xor(by1, o));
+        bx0 = min(bx0, __shfl_xor(bx0, o)); bx1 = max(bx1, __shfl_xor(bx1, o));
+      }
+      if (threadIdx.x == 0) {
+        bbox[img * 4 + 0] = by0; bbox[img * 4 + 1] = by1;
+        bbox[img * 4 + 2] = bx0; bbox[img * 4 + 3] = bx1;
+      }
+    }
   }
 }
 
@@ -684,6 +702,7 @@ struct EncPlan {
   size_t x_sz, t1_sz, t2_sz;  // per-image extents of x0/x1/ds, t1, t2 (floats)
   int *list_idx, *list_n;
   float* list_w;
+  int* bbox;  // [n][4]: level-0 bounding box of the listed pixels
 };
 
 static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
@@ -727,6 +746,7 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   pl->list_idx = a.get<int>((size_t)n * lv.per_image);
   pl->list_w = a.get<float>((size_t)n * lv.per_image);
   pl->list_n = a.get<int>((size_t)n * 5);
+  pl->bbox = a.get<int>((size_t)n * 4);
   return 0;
 }
 
@@ -870,11 +890,11 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   } else if (masks == nullptr || mask_dtype == MILAN_DTYPE_U8)
     hipLaunchKernelGGL(mask_pyramid_kernel<uint8_t>, dim3(n, 5), dim3(256), 0, s,
                        (const uint8_t*)masks, H, W, pl.lv, pl.list_idx,
-                       pl.list_w, pl.list_n);
+                       pl.list_w, pl.list_n, pl.bbox);
   else
     hipLaunchKernelGGL(mask_pyramid_kernel<float>, dim3(n, 5), dim3(256), 0, s,
                        (const float*)masks, H, W, pl.lv, pl.list_idx, pl.list_w,
-                       pl.list_n);
+                       pl.list_n, pl.bbox);
   MILAN_CHECK_HIP(hipGetLastError());
 
   // split-f16 mode needs every bottleneck conv to have a split weight copy
@@ -949,6 +969,26 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       g.out_split = 0;  // the raw fp32 output is pyramid tap 0
       g.flop_k = c->stem.kh * c->stem.kw * c->stem.cin_real;  // 7x7x3 = 147
     }
+    const bool fused_stem = pair_stem && (c->fusion & MILAN_FUSE_STEM) &&
+                            stem_fused_supported(c->stem_pair.cout, c->stem_pair.Kp);
+    if (fused_stem) {
+      // conv1 + bn1 + ReLU + maxpool in one persistent launch (stem.hip); the raw
+      // tensor is only materialised where the level-0 pooling will read it
+      StemArgs sa{};
+      sa.in = pl.in4; sa.ws = c->stem_pair.ws; sa.bias = c->stem_pair.bias;
+      sa.acc_scale = c->stem_pair.ws_inv;
+      sa.scale = c->bn1_scale; sa.shift = c->bn1_shift;
+      sa.raw = spatial ? nullptr : pl.raw; sa.y = pl.x0;
+      sa.bbox = spatial ? nullptr : pl.bbox;
+      sa.zero = c->zero;
+      sa.n = n; sa.H = H; sa.G = G; sa.h1 = pl.h1; sa.w1 = pl.w1;
+      sa.hp = pl.hp; sa.wp = pl.wp;
+      {
+        StageScope scope(MILAN_STAGE_ENC_STEM, s);
+        MILAN_TRY(launch_stem_fused(sa, s));
+      }
+      MILAN_TRY(pool(pl.raw, 0, wd, 0));
+    } else {
     {
       StageScope scope(MILAN_STAGE_ENC_STEM, s);
       MILAN_TRY(launch_gemm(g, s));
@@ -968,6 +1008,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                          (const float4*)c->bn1_shift, (float4*)pl.x0);
     MILAN_CHECK_HIP(hipGetLastError());
     stage.reset();
+    }
   }
 
   // 4. bottleneck stages; tap after each stage
