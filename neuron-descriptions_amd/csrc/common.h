@@ -152,6 +152,7 @@ struct StemArgs {
   const float* zero;    // >= 64 B of zeros
   int n, H, G, h1, w1, hp, wp;
   int tiles_y, tiles_x;  // filled by the launcher
+  int debug;             // timing experiments: 1 no MFMA, 2 no store phase, 4 no DMA, 8 no staging
 };
 bool stem_fused_supported(int cout, int Kp);
 int launch_stem_fused(const StemArgs& a, hipStream_t s);

@@ -25,6 +25,8 @@
 // outputs are bitwise those of the three launches (tests/test_gpu_stem.py).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace milan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,19 +36,41 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+// timing ablations (StemArgs::debug) exist in the experiments build only
+#if MILAN_EXPERIMENTS
+#define STEM_ABLATE(bit) (a.debug & (bit))
+#else
+#define STEM_ABLATE(bit) false
+#endif
+
 namespace {
 
-constexpr int kPoolR = 7, kPoolC = 8;            // pooled pixels per tile
-constexpr int kConvR = 2 * kPoolR + 1;           // 15 conv rows (one halo row above)
-constexpr int kConvC = 2 * kPoolC + 1;           // 17 conv columns (one halo column left)
-constexpr int kInR = 2 * (kConvR - 1) + 7;       // 35 input rows
-constexpr int kInC = kConvC + 3;                 // 20 pixel-pair groups per input row
-constexpr int kPieces = kInR * kInC;             // 16-byte pieces per plane (hi / lo)
-constexpr int kDma = (2 * kPieces + 63) / 64;    // wave-wide DMA instructions per tile
-constexpr int kInBytes = kDma * 1024;            // one input buffer
-constexpr int kSRow = 68;                        // staging row stride (floats)
-constexpr int kSlabs = 14;                       // K = 224 slots = 14 x 16
-static_assert(kConvR * kConvC <= 256, "conv tile = 8 MFMA row blocks");
+constexpr int kSRow = 68;    // staging row stride (floats)
+constexpr int kSlabs = 14;   // K = 224 slots = 14 x 16
+
+// Tile geometry: PR x PC pooled pixels per workgroup of NW waves.
+//   <7, 8, 8>: 15 x 17 conv pixels (255 of 256 MFMA rows), one workgroup per CU
+//   <3, 8, 4>:  7 x 17 conv pixels (119 of 128), 59 KB of LDS: two workgroups per CU,
+//              whose store phases (VALU / LDS / HBM) run under each other's MFMA phase
+template <int PR, int PC, int NW>
+struct StemTile {
+  static constexpr int kPoolR = PR, kPoolC = PC;
+  static constexpr int kConvR = 2 * PR + 1;            // one halo row above
+  static constexpr int kConvC = 2 * PC + 1;            // one halo column left
+  static constexpr int kPix = kConvR * kConvC;
+  static constexpr int kMB = (kPix + 31) / 32;         // 32-pixel MFMA row blocks
+  static constexpr int kMBW = kMB / (NW / 2);          // row blocks per wave
+  static constexpr int kInR = 2 * (kConvR - 1) + 7;    // input rows
+  static constexpr int kInC = kConvC + 3;              // pixel-pair groups per input row
+  static constexpr int kPieces = kInR * kInC;          // 16-byte pieces per plane (hi / lo)
+  static constexpr int kDma = (2 * kPieces + 63) / 64; // wave-wide DMA instructions per tile
+  static constexpr int kDmaW = (kDma + NW - 1) / NW;   // per wave
+  static constexpr int kInBytes = kDma * 1024;         // one input buffer
+  static constexpr int kRawIt = kMB * 32 * 16 / (NW * 64);
+  static constexpr size_t kLds = 2 * (size_t)kInBytes + sizeof(float) * kMB * 32 * kSRow;
+  static_assert(kMB % (NW / 2) == 0, "row blocks split evenly over the waves");
+  static_assert(PR * PC * 8 <= NW * 64, "one pooling work item per thread");
+};
 
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
@@ -65,13 +89,18 @@ __device__ inline void stem_split8(const float* v, f32x4* hi_out, f32x4* lo_out)
 
 }  // namespace
 
-__global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
+template <int PR, int PC, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(StemArgs a) {
   // roundings as written (the unfused path rounds acc * scale before the bias add
   // because an LDS round trip sits between them); the one fused multiply-add of the
   // bn step is spelled __builtin_fmaf
 #pragma clang fp contract(off)
+  using T = StemTile<PR, PC, NW>;
+  constexpr int kPoolR = T::kPoolR, kPoolC = T::kPoolC, kConvR = T::kConvR, kConvC = T::kConvC;
+  constexpr int kInC = T::kInC, kPieces = T::kPieces, kDma = T::kDma, kInBytes = T::kInBytes;
+  constexpr int kMBW = T::kMBW;
   extern __shared__ __attribute__((aligned(16))) char stem_smem[];
-  float* stg = reinterpret_cast<float*>(stem_smem + 2 * kInBytes);  // [256][kSRow]
+  float* stg = reinterpret_cast<float*>(stem_smem + 2 * kInBytes);  // [32 kMB][kSRow]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -91,12 +120,12 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
   }
   const float bias_n = a.bias ? a.bias[nb * 32 + (lane & 31)] : 0.f;
 
-  // ---- loader: DMA instruction d = wave + 8 k moves pieces 64 d .. 64 d + 63 ----
-  int ld_row[3], ld_col[3], ld_off[3];
-  bool ld_ok[3];
+  // ---- loader: DMA instruction d = wave + NW k moves pieces 64 d .. 64 d + 63 ----
+  int ld_row[T::kDmaW], ld_col[T::kDmaW], ld_off[T::kDmaW];
+  bool ld_ok[T::kDmaW];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = (wave + 8 * k) * 64 + lane;
+  for (int k = 0; k < T::kDmaW; ++k) {
+    const int i = (wave + NW * k) * 64 + lane;
     const int plane = i >= kPieces ? 1 : 0;
     const int gi = i - plane * kPieces;
     ld_ok[k] = i < 2 * kPieces;
@@ -107,65 +136,67 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
   const int tiles = a.tiles_y * a.tiles_x;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   // tile sequence of this workgroup: XCD x walks images x, x + 8, ... tile by tile,
-  // its workgroups taking consecutive tiles (halo rows / columns meet in that L2)
-  auto decode = [&](int it, int* img, int* ta, int* tb) -> bool {
-    const long q = (long)it * nslots + slot;
-    const int gidx = (int)(q / tiles);
-    const int ti = (int)(q - (long)gidx * tiles);
-    *img = gidx * 8 + xcd;
-    *ta = ti / a.tiles_x;
-    *tb = ti - *ta * a.tiles_x;
+  // its workgroups taking consecutive tiles (halo rows / columns meet in that L2).
+  // (seq_g, seq_t) = (image group, tile in image) of the NEXT tile to decode.
+  int seq_g = slot / tiles, seq_t = slot - seq_g * tiles;
+  auto decode = [&](int* img, int* ta, int* tb) -> bool {
+    *img = seq_g * 8 + xcd;
+    *ta = seq_t / a.tiles_x;
+    *tb = seq_t - *ta * a.tiles_x;
+    seq_t += nslots;
+    while (seq_t >= tiles) { seq_t -= tiles; ++seq_g; }
     return *img < a.n;
   };
   auto issue = [&](int img, int ta, int tb, int buf) {
     const int iy0 = 2 * (2 * kPoolR * ta - 1) - 3, ig0 = 2 * kPoolC * tb - 2;
     char* dst = stem_smem + buf * kInBytes;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (wave + 8 * k < kDma) {
+    for (int k = 0; k < T::kDmaW; ++k) {
+      if (wave + NW * k < kDma) {
         const int iy = iy0 + ld_row[k], ig = ig0 + ld_col[k];
         const bool ok = ld_ok[k] && iy >= 0 && iy < a.H && ig >= 0 && ig < a.G;
         const float* src =
             ok ? a.in + (((long)img * a.H + iy) * a.G + ig) * 8 + ld_off[k] : a.zero;
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
-                                         (LDS_AS void*)(dst + (wave + 8 * k) * 1024),
+                                         (LDS_AS void*)(dst + (wave + NW * k) * 1024),
                                          16, 0, 0);
       }
     }
   };
 
   // ---- A fragment addresses: pixel t = 32 (2 mp + i) + lane % 32 of the tile ----
-  int abase[2];
+  int abase[kMBW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int t = (2 * mp + i) * 32 + (lane & 31);
+  for (int i = 0; i < kMBW; ++i) {
+    int t = (kMBW * mp + i) * 32 + (lane & 31);
     t = t < kConvR * kConvC ? t : kConvR * kConvC - 1;
     const int pr = t / kConvC, pc = t - pr * kConvC;
-    abase[i] = ((2 * pr) * kInC + pc + 2 * 0 + half) * 16;
+    abase[i] = ((2 * pr) * kInC + pc + half) * 16;
   }
   // slab s = k-groups 2s, 2s+1: kernel row s/2, group column 2 (s%2) + half
 
   // ---- store-phase constants ------------------------------------------------
   // raw rows: iteration it handles pixel 32 it + tid/16, channels 4 (tid%16) ..
-  unsigned raw_rc[8];
+  unsigned raw_rc[T::kRawIt];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int t = it * 32 + (tid >> 4);
+  for (int it = 0; it < T::kRawIt; ++it) {
+    const int t = it * (NW * 4) + (tid >> 4);
     const int pr = t / kConvC, pc = t - pr * kConvC;
     const bool own = t < kConvR * kConvC && pr >= 1 && pc >= 1;
     raw_rc[it] = own ? (unsigned)(pr << 8 | pc) : 0xffffu;
   }
   const int po = tid >> 3, c8 = tid & 7;
-  const int py = po >> 3, px = po & 7;  // po < 56 for the pooling threads
-  float sc[8], sh[8];
+  const int py = po / kPoolC, px = po - py * kPoolC;  // po < PR * PC for the pooling threads
+  float sc[8], sh[8], sg[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     sc[e] = a.scale[c8 * 8 + e];
     sh[e] = a.shift[c8 * 8 + e];
+    sg[e] = sc[e] < 0.f ? -1.f : 1.f;
   }
 
   int img, ta, tb;
-  bool have = decode(0, &img, &ta, &tb);
+  bool have = decode(&img, &ta, &tb);
   if (have) issue(img, ta, tb, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -173,27 +204,28 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
   for (int it = 0; have; ++it) {
     const int buf = it & 1;
     int nimg, nta, ntb;
-    const bool nhave = decode(it + 1, &nimg, &nta, &ntb);
-    if (nhave) issue(nimg, nta, ntb, buf ^ 1);
+    const bool nhave = decode(&nimg, &nta, &ntb);
+    if (nhave && !STEM_ABLATE(4)) issue(nimg, nta, ntb, buf ^ 1);
 
     // ---- conv1 on the matrix cores ----
-    f32x16 acc[2], accx[2];
+    f32x16 acc[kMBW], accx[kMBW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kMBW; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
     const char* cur = stem_smem + buf * kInBytes;
+    if (!STEM_ABLATE(1))
 #pragma unroll
     for (int s = 0; s < kSlabs; ++s) {
       const int off = ((s >> 1) * kInC + 2 * (s & 1)) * 16;
-      f32x4 ah[2], al[2];
+      f32x4 ah[kMBW], al[kMBW];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < kMBW; ++i) {
         ah[i] = *reinterpret_cast<const f32x4*>(cur + abase[i] + off);
         al[i] = *reinterpret_cast<const f32x4*>(cur + abase[i] + off + kPieces * 16);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < kMBW; ++i) {
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[i]), h8(bh[s]), acc[i], 0, 0, 0);
         accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[i]), h8(bl[s]), accx[i], 0, 0, 0);
         accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[i]), h8(bh[s]), accx[i], 0, 0, 0);
@@ -202,13 +234,14 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
 
     // staging tile free again (every wave is past the previous tile's store phase)
     __builtin_amdgcn_s_barrier();
+    if (!STEM_ABLATE(8))
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kMBW; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const float v = (acc[i][r] + accx[i][r]) * a.acc_scale + bias_n;
-        stg[((2 * mp + i) * 32 + row) * kSRow + nb * 32 + (lane & 31)] = v;
+        stg[((kMBW * mp + i) * 32 + row) * kSRow + nb * 32 + (lane & 31)] = v;
       }
     // next tile's input has had the whole MFMA loop to land
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -216,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
 
     // ---- (a) raw conv1 rows for the level-0 masked pooling ----
     const int cr0 = 2 * kPoolR * ta - 1, cc0 = 2 * kPoolC * tb - 1;
-    if (a.raw) {
+    if (a.raw && !STEM_ABLATE(2)) {
       int y0 = 0, y1 = a.h1 - 1, x0 = 0, x1 = a.w1 - 1;
       if (a.bbox) {
         const int* bb = a.bbox + (long)img * 4;
@@ -226,11 +259,11 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
         y1 = y1 < a.h1 - 1 ? y1 : a.h1 - 1;
         x1 = x1 < a.w1 - 1 ? x1 : a.w1 - 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < T::kRawIt; ++j) {
           const int pr = raw_rc[j] >> 8, pc = raw_rc[j] & 255;
           const int r = cr0 + pr, c = cc0 + pc;
           if (raw_rc[j] != 0xffffu && r >= y0 && r <= y1 && c >= x0 && c <= x1) {
-            const int t = j * 32 + (tid >> 4);
+            const int t = j * (NW * 4) + (tid >> 4);
             const f32x4 v =
                 *reinterpret_cast<const f32x4*>(stg + t * kSRow + (tid & 15) * 4);
             *reinterpret_cast<f32x4*>(a.raw + (((long)img * a.h1 + r) * a.w1 + c) * 64 +
@@ -242,7 +275,11 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
     // ---- (b) bn1 + ReLU + 3x3/2 max pooling -> split format ----
     {
       const int ho = kPoolR * ta + py, wo = kPoolC * tb + px;
-      if (po < kPoolR * kPoolC && ho < a.hp && wo < a.wp) {
+      if (po < kPoolR * kPoolC && ho < a.hp && wo < a.wp && !STEM_ABLATE(2)) {
+        // max_i relu(round(v_i * sc + sh)) == relu(round(sel_i(v_i) * sc + sh)) with sel =
+        // max for sc >= 0, min for sc < 0: x -> round(x * sc + sh) is monotone, so the
+        // window maximum can be taken BEFORE bn (on sg * v, sg = +-1 exact) -- two thirds
+        // of the VALU work of the per-pixel form, same bits
         float best[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
@@ -259,12 +296,14 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              best[e] = fmaxf(best[e], fmaxf(__builtin_fmaf(u[e], sc[e], sh[e]), 0.f));
-              best[4 + e] =
-                  fmaxf(best[4 + e], fmaxf(__builtin_fmaf(w[e], sc[4 + e], sh[4 + e]), 0.f));
+              best[e] = fmaxf(best[e], u[e] * sg[e]);
+              best[4 + e] = fmaxf(best[4 + e], w[e] * sg[4 + e]);
             }
           }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          best[e] = fmaxf(__builtin_fmaf(best[e] * sg[e], sc[e], sh[e]), 0.f);
         f32x4 hi4, lo4;
         stem_split8(best, &hi4, &lo4);
         float* d = a.y + ((((long)img * a.hp + ho) * a.wp + wo) * 8 + c8) * 8;
@@ -278,13 +317,29 @@ __global__ __launch_bounds__(512, 1) void stem_fused_kernel(StemArgs a) {
 
 bool stem_fused_supported(int cout, int Kp) { return cout == 64 && Kp == 224; }
 
-int launch_stem_fused(const StemArgs& a0, hipStream_t s) {
-  StemArgs a = a0;
+template <int PR, int PC, int NW>
+static int launch_stem_cfg(StemArgs a, int cus, hipStream_t s) {
+  using T = StemTile<PR, PC, NW>;
+  a.tiles_y = (a.hp + PR - 1) / PR;
+  a.tiles_x = (a.wp + PC - 1) / PC;
+  auto kern = stem_fused_kernel<PR, PC, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)T::kLds));
+    attr_set = true;
+  }
+  // persistent: one workgroup per CU (8 waves) or two (4 waves each)
+  hipLaunchKernelGGL(kern, dim3(cus * (NW == 8 ? 1 : 2)), dim3(NW * 64), T::kLds, s, a);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_stem_fused(const StemArgs& a, hipStream_t s) {
   MILAN_REQUIRE(a.n > 0 && a.H > 0 && a.G > 0 && a.in && a.ws && a.y && a.scale &&
                     a.shift && a.zero,
                 MILAN_ERR_ARG, "stem: missing operand");
-  a.tiles_y = (a.hp + kPoolR - 1) / kPoolR;
-  a.tiles_x = (a.wp + kPoolC - 1) / kPoolC;
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -292,24 +347,23 @@ int launch_stem_fused(const StemArgs& a0, hipStream_t s) {
     MILAN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     cus = cus < 8 ? 8 : cus / 8 * 8;
   }
-  const size_t lds = 2 * (size_t)kInBytes + sizeof(float) * 256 * kSRow;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-    attr_set = true;
-  }
   // algorithmic work: 7x7x3 taps per conv1 output; bytes: input groups once, raw
   // fp32 out, pooled split out
   const double px1 = (double)a.n * a.h1 * a.w1, pxp = (double)a.n * a.hp * a.wp;
   void* rec = gemm_profile_begin(
       2.0 * px1 * 64 * 147,
       32.0 * a.n * a.H * a.G + (a.raw ? 256.0 * px1 : 0.0) + 256.0 * pxp, s);
-  hipLaunchKernelGGL(stem_fused_kernel, dim3(cus), dim3(512), lds, s, a);
+  int r;
+#if MILAN_EXPERIMENTS
+  // MILAN_STEM_TILE=0: 3 x 8 pooled pixels per 4-wave workgroup, two per CU (measured
+  // slower: 5.8 against 5.3 ms per 256 neurons, profiles/r3_experiments.txt)
+  static const int variant = getenv("MILAN_STEM_TILE") ? atoi(getenv("MILAN_STEM_TILE")) : 1;
+  if (variant == 0) r = launch_stem_cfg<3, 8, 4>(a, cus, s);
+  else
+#endif
+  r = launch_stem_cfg<7, 8, 8>(a, cus, s);
   gemm_profile_end(rec, s);
-  MILAN_CHECK_HIP(hipGetLastError());
-  return 0;
+  return r;
 }
 
 }  // namespace milan

@@ -28,6 +28,10 @@ def ctx(dev):
     # a narrow trunk behind the full-width (64-channel) stem keeps the test fast
     sd = synthetic.resnet_state_dict('resnet50', seed=5, width=64,
                                      prefix='encoder.encoder.model.')
+    # negative and zero bn1 scales: the kernel pools before bn on sign-flipped values
+    w = sd['encoder.encoder.model.bn1.weight']
+    w[1::3] = -w[1::3]
+    w[5] = 0.
     c = hip.Context(hip.make_dims(sd, 10, blocks=synthetic.RESNET_BLOCKS['resnet50']),
                     sd, dev)
     c.set_precision('split_f16')
