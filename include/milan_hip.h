@@ -231,11 +231,15 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
  *                     launch over LDS-resident input tiles (csrc/stem.hip; the raw
  *                     conv1 tensor, pyramid level 0 of encoders.py:303-320, is only
  *                     materialised where the mask-weighted pooling reads it).
- * Default: MILAN_FUSE_CHAIN | MILAN_FUSE_STEM (environment MILAN_CHAIN=<flags>
+ *   MILAN_FUSE_CONV3  the 64 -> 64 channel 3x3 convolutions of layer1 as a persistent
+ *                     kernel with register-resident weights and an LDS-resident input
+ *                     tile (csrc/conv3.hip) instead of the implicit GEMM.
+ * Default: MILAN_FUSE_CHAIN | MILAN_FUSE_STEM | MILAN_FUSE_CONV3 (environment MILAN_CHAIN=<flags>
  * overrides at context creation). */
 enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
        MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): one wave per SIMD */
-       MILAN_FUSE_STEM = 4 };
+       MILAN_FUSE_STEM = 4,
+       MILAN_FUSE_CONV3 = 8 };     /* layer1's 3x3 convs: weights in registers (csrc/conv3.hip) */
 int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);

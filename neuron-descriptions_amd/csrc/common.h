@@ -156,6 +156,19 @@ struct StemArgs {
 };
 bool stem_fused_supported(int cout, int Kp);
 int launch_stem_fused(const StemArgs& a, hipStream_t s);
+// ---- 3x3 / 1 / 1 convolution, 64 -> 64 channels, weights in registers (conv3.hip) ----
+struct Conv3Args {
+  const float* in;     // [n][h][w][64] split format
+  const float* ws;     // split weights [64][576] (k = tap * 64 + channel), scaled
+  const float* bias;   // [64] or nullptr
+  float acc_scale;     // 1 / weight scale
+  float* out;          // [n][h][w][64] split format: relu(conv + bias)
+  const float* zero;   // >= 64 B of zeros
+  int n, h, w;
+  int tiles_y, tiles_x;  // filled by the launcher
+};
+bool conv3_p64_supported(int cin, int cout, int kh, int kw, int stride, int pad);
+int launch_conv3_p64(const Conv3Args& a, hipStream_t s);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, long long* launches);
 int profile_read_stages(double* table /* [MILAN_STAGE_COUNT][6] */);
@@ -266,7 +279,7 @@ struct milan_ctx {
   milan_dims d{};
   bool finalized = false;
   int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16
-  int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_STEM;  // milan_set_fusion
+  int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_STEM | MILAN_FUSE_CONV3;  // milan_set_fusion
   // hipGraph cache of whole decode passes (milan_set_graph_capture)
   int graph_capture = 0;
   struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int seen = 0; };

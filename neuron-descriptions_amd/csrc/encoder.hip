@@ -1049,7 +1049,17 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       t1_ready = false;
       GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU,
                               nullptr, c->zero, &h2, &w2, split);
-      MILAN_TRY(launch_gemm(g2, s));
+      if (split && (c->fusion & MILAN_FUSE_CONV3) && b.c2.K == b.c2.Kp &&
+          conv3_p64_supported(b.c2.cin, b.c2.cout, b.c2.kh, b.c2.kw, b.c2.stride,
+                              b.c2.pad)) {
+        // layer1's 3x3: weights in registers, input tile staged once (conv3.hip)
+        Conv3Args ca{};
+        ca.in = pl.t1; ca.ws = b.c2.ws; ca.bias = b.c2.bias; ca.acc_scale = b.c2.ws_inv;
+        ca.out = pl.t2; ca.zero = c->zero; ca.n = n; ca.h = h1; ca.w = w1;
+        MILAN_TRY(launch_conv3_p64(ca, s));
+      } else {
+        MILAN_TRY(launch_gemm(g2, s));
+      }
       const float* identity = x;
       // Expand conv of this block + reduce conv of the next one in ONE launch: the
       // 4P-channel block output is written once and not read back by the next c1.
