@@ -166,6 +166,8 @@ struct Conv3Args {
   const float* zero;   // >= 64 B of zeros
   int n, h, w;
   int tiles_y, tiles_x;  // filled by the launcher
+  int debug;             // timing experiments: 1 no MFMA, 2 no epilogue, 4 no DMA, 8 no hand-over
+  long long* prof;       // experiments build: per-phase cycle sums of workgroup 0 (16 values)
 };
 bool conv3_p64_supported(int cin, int cout, int kh, int kw, int stride, int pad);
 int launch_conv3_p64(const Conv3Args& a, hipStream_t s);

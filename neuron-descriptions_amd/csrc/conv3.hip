@@ -16,8 +16,9 @@
 //   * the accumulation order of the implicit-GEMM kernel (one accumulator, k
 //     ascending, hl / lh / hh per slab) is kept by handing the accumulator from the
 //     first-half wave to the second-half wave through LDS: in step s the first-half
-//     waves multiply block s while the second-half waves finish block s - 1 and run
-//     its epilogue (scale, + bias, ReLU, split, store).  One s_barrier per step.
+//     waves multiply block s while the second-half waves first store block s - 2
+//     (scale, + bias, ReLU, split: VALU / LDS / HBM work under the other waves' MFMAs)
+//     and then finish block s - 1.  One s_barrier per step.
 // Results are bitwise those of launch_gemm on the same layer (tests/test_gpu_conv3.py).
 #include "common.h"
 
@@ -30,6 +31,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+// timing ablations (Conv3Args::debug) exist in the experiments build only
+#if MILAN_EXPERIMENTS
+#define C3_ABLATE(bit) (a.debug & (bit))
+#else
+#define C3_ABLATE(bit) false
+#endif
+
 namespace {
 
 constexpr int kTR = 8, kTC = 14;           // output pixels per tile (112 of 128 MFMA rows)
@@ -39,7 +47,7 @@ constexpr int kRing = 3;                   // input tiles in LDS
 constexpr int kBatch = 5;                  // DMA instructions per first-half wave and step
 constexpr int kHalfSlabs = 18;             // k-slabs (16 slots) per K half; K = 576 = 36 slabs
 constexpr int kHandBytes = 4096;           // one accumulator: 16 registers x 64 lanes
-constexpr size_t kLds = (size_t)kRing * kInBytes + 4 * 2 * kHandBytes;
+constexpr size_t kLds = (size_t)kRing * kInBytes + 4 * 2 * kHandBytes + 4 * 2048;  // = 160 KB
 static_assert(kIR * kIC * 16 == 4 * 2 * kBatch * 64, "two batches of the four loader waves = one tile");
 
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
@@ -67,31 +75,36 @@ __device__ __forceinline__ void c3_mfma(const char* buf, int pbase, int pc, int 
   // reads and waits (the compiler drains lgkmcnt to 0 in front of every MFMA group,
   // which would put the latency of the prefetch back on the critical path); the wait
   // names the fragment registers, which keeps the MFMAs behind it.
-  f32x4 ah[2], al[2];
-  auto fetch = [&](int s, int b2) {
+  f32x4 ah[3], al[3];
+  auto fetch = [&](int s, int b3) {
     const int sg = KH * kHalfSlabs + s;
     const int tap = sg >> 2, kh = tap / 3, kw = tap - kh * 3;
     const int jh = ((4 * sg) & 15) + 2 * half;  // 16-byte slot of the hi piece
     const int x = pc + kw;                      // input column = swizzle key
     const char* p = buf + pbase + (kh * kIC + kw) * 256;
     asm volatile("ds_read_b128 %0, %1"
-                 : "=v"(ah[b2]) : "v"((LDS_AS const char*)(p + ((jh ^ x) << 4))) : "memory");
+                 : "=v"(ah[b3]) : "v"((LDS_AS const char*)(p + ((jh ^ x) << 4))) : "memory");
     asm volatile("ds_read_b128 %0, %1"
-                 : "=v"(al[b2]) : "v"((LDS_AS const char*)(p + (((jh + 1) ^ x) << 4))) : "memory");
+                 : "=v"(al[b3]) : "v"((LDS_AS const char*)(p + (((jh + 1) ^ x) << 4))) : "memory");
   };
+  // two slabs ahead: a wave alone on its SIMD (its partner is in the epilogue) must
+  // cover the whole LDS latency by itself
   fetch(0, 0);
+  fetch(1, 1);
 #pragma unroll
   for (int s = 0; s < kHalfSlabs; ++s) {
-    const int b2 = s & 1;
-    if (s + 1 < kHalfSlabs) {
-      fetch(s + 1, b2 ^ 1);
-      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[b2]), "+v"(al[b2]) :: "memory");
+    const int b3 = s % 3;
+    if (s + 2 < kHalfSlabs) {
+      fetch(s + 2, (s + 2) % 3);
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[b3]), "+v"(al[b3]) :: "memory");
+    } else if (s + 1 < kHalfSlabs) {
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[b3]), "+v"(al[b3]) :: "memory");
     } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[b2]), "+v"(al[b2]) :: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[b3]), "+v"(al[b3]) :: "memory");
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[b2]), h8(bl[s]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[b2]), h8(bh[s]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[b2]), h8(bh[s]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[b3]), h8(bl[s]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[b3]), h8(bh[s]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[b3]), h8(bh[s]), acc, 0, 0, 0);
   }
 }
 
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
   auto issue_batch = [&](int g) -> bool {
     const int i = g >> 1;
     int img, ty, tx;
-    if (i >= ntile || !decode(i, &img, &ty, &tx)) return false;
+    if (i >= ntile || !decode(i, &img, &ty, &tx) || C3_ABLATE(4)) return false;
     char* dst = c3_smem + (i % kRing) * kInBytes;
     const int ix = tx * kTC - 1 + ld_c;
     const bool xok = ix >= 0 && ix < a.w;
@@ -188,73 +201,106 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
   }
   __builtin_amdgcn_s_barrier();
 
-  // step s: first-half waves multiply block s, second-half waves block s - 1
-  const int nsteps = 2 * ntile + 1;
-  for (int s = 0; s < nsteps; ++s) {
-    const int blk = kh2 == 0 ? s : s - 1;          // this wave's block in the sequence
-    const bool work = blk >= 0 && blk < 2 * ntile;
-    const int ti = blk >> 1, b = blk & 1;
-    const char* buf = c3_smem + (ti % kRing) * kInBytes;
-    char* hslot = hand + (pair * 2 + (blk & 1)) * kHandBytes;
-    f32x16 acc;
-    if (kh2 == 0) {
-      const bool issued = issue_batch(s + 3);
+  // step s: first-half waves multiply block s and hand it over; second-half waves store
+  // block s - 2 (epilogue, under the first-half waves' MFMAs) and then finish block s - 1
+  const int nblk = 2 * ntile;
+  const int nsteps = nblk + 2;
+#if MILAN_EXPERIMENTS
+  long long pt[4] = {0, 0, 0, 0}, t0 = clock64();
+#define C3_STAMP(k) do { const long long t1 = clock64(); pt[k] += t1 - t0; t0 = t1; } while (0)
+#else
+#define C3_STAMP(k) do {} while (0)
+#endif
+  if (kh2 == 0) {
+    for (int s = 0; s < nsteps; ++s) {
+      if (s < nblk) {
+        const int ti = s >> 1, b = s & 1;
+        const char* buf = c3_smem + (ti % kRing) * kInBytes;
+        char* hslot = hand + (pair * 2 + b) * kHandBytes;
+        f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      if (work) {
-        c3_mfma<0>(buf, pbase[b], pcol[b], half, bh, bl, acc);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (!C3_ABLATE(1)) c3_mfma<0>(buf, pbase[b], pcol[b], half, bh, bl, acc);
+        if (!C3_ABLATE(8))
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          *reinterpret_cast<f32x4*>(hslot + q * 1024 + lane * 16) = v;
-        }
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(hslot + q * 1024 + lane * 16) = v;
+          }
       }
+      C3_STAMP(0);
       // every batch but the one issued in this step has landed: the tile the next step
       // starts is whole
-      if (issued) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kBatch) : "memory");
+      if (issue_batch(s + 3)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kBatch) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    } else if (work) {
+      C3_STAMP(1);
+      __builtin_amdgcn_s_barrier();
+      C3_STAMP(2);
+    }
+  } else {
+    float* stg = reinterpret_cast<float*>(hand + 4 * 2 * kHandBytes + pair * 2048);  // [16][32]
+    f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(hslot + q * 1024 + lane * 16);
-        acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
-      }
-      c3_mfma<1>(buf, pbase[b], pcol[b], half, bh, bl, acc);
-      // epilogue through the (consumed) hand-over slot: [32 pixels][32 channels] fp32
-      float* stg = reinterpret_cast<float*>(hslot);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s = 0; s < nsteps; ++s) {
+      if (s >= 2 && s - 2 < nblk && !C3_ABLATE(2)) {
+        // ---- epilogue of block s - 2: scale, + bias, ReLU, split, store ----
+        const int ti = (s - 2) >> 1, b = (s - 2) & 1;
+        int img, ty, tx;
+        decode(ti, &img, &ty, &tx);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        stg[row * 32 + (lane & 31)] = acc[r] * a.acc_scale;
-      }
-      int img, ty, tx;
-      decode(ti, &img, &ty, &tx);
+        for (int it = 0; it < 2; ++it) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 16 + (lane >> 2);
-        const int t = (mg * 2 + b) * 32 + row;
-        const int pr = t / kTC, pc = t - pr * kTC;
-        const int oy = ty * kTR + pr, ox = tx * kTC + pc;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * 32 + e_g * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * 32 + e_g * 8 + 4);
-        if (t < kTR * kTC && oy < a.h && ox < a.w) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = fmaxf(v0[e] + bias8[e], 0.f);
-            v[4 + e] = fmaxf(v1[e] + bias8[4 + e], 0.f);
+          for (int r = 0; r < 8; ++r) {
+            const int lrow = (r & 3) + 8 * (r >> 2) + 4 * half;  // rows 16 it .. 16 it + 15
+            stg[lrow * 32 + (lane & 31)] = acc[8 * it + r] * a.acc_scale;
           }
-          f32x4 hi, lo;
-          c3_split8(v, &hi, &lo);
-          float* d = a.out + (((long)img * a.h + oy) * a.w + ox) * 64 + nb * 32 + e_g * 8;
-          *reinterpret_cast<f32x4*>(d) = hi;
-          *reinterpret_cast<f32x4*>(d + 4) = lo;
+          const int row = it * 16 + (lane >> 2);
+          const int t = (mg * 2 + b) * 32 + row;
+          const int pr = t / kTC, pc = t - pr * kTC;
+          const int oy = ty * kTR + pr, ox = tx * kTC + pc;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + (lane >> 2) * 32 + e_g * 8);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + (lane >> 2) * 32 + e_g * 8 + 4);
+          if (t < kTR * kTC && oy < a.h && ox < a.w) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = fmaxf(v0[e] + bias8[e], 0.f);
+              v[4 + e] = fmaxf(v1[e] + bias8[4 + e], 0.f);
+            }
+            f32x4 hi, lo;
+            c3_split8(v, &hi, &lo);
+            float* d = a.out + (((long)img * a.h + oy) * a.w + ox) * 64 + nb * 32 + e_g * 8;
+            *reinterpret_cast<f32x4*>(d) = hi;
+            *reinterpret_cast<f32x4*>(d + 4) = lo;
+          }
         }
       }
+      C3_STAMP(0);
+      if (s >= 1 && s - 1 < nblk) {
+        const int ti = (s - 1) >> 1, b = (s - 1) & 1;
+        const char* buf = c3_smem + (ti % kRing) * kInBytes;
+        const char* hslot = hand + (pair * 2 + b) * kHandBytes;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (!C3_ABLATE(8))
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(hslot + q * 1024 + lane * 16);
+            acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+          }
+        if (!C3_ABLATE(1)) c3_mfma<1>(buf, pbase[b], pcol[b], half, bh, bl, acc);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      C3_STAMP(1);
+      __builtin_amdgcn_s_barrier();
+      C3_STAMP(2);
     }
-    __builtin_amdgcn_s_barrier();
   }
+#if MILAN_EXPERIMENTS
+  if (a.prof && blockIdx.x == 0 && lane == 0 && pair == 0)
+    for (int k = 0; k < 4; ++k) a.prof[kh2 * 4 + k] = pt[k];
+#endif
 }
 
 bool conv3_p64_supported(int cin, int cout, int kh, int kw, int stride, int pad) {
