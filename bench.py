@@ -254,7 +254,7 @@ def measure_traffic_live(args):
             q = ('select kernel_name, count(*), sum(value) from counters_collection '
                  'where counter_name = ? group by kernel_name')
             for name, launches, total in db.execute(q, (counter,)):
-                if 'igemm' in name or 'chain_kernel' in name:
+                if any(k in name for k in ('igemm', 'chain_kernel', 'stem_fused', 'conv3_p64')):
                     totals.setdefault(name, {})[counter] = (launches, total)
     best = None
     for name, t in totals.items():
@@ -331,13 +331,20 @@ def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
     hbm('encoder.input', 'enc_input',
         'mask pyramid lists + u8 -> normalised NHWC input (u8 image + u8 mask '
         'read, 16 B/pixel written)', 3 * hw + hw + 16 * hw)
-    mfma('encoder.stem', ['enc_stem'], 'conv1 7x7/2 (implicit GEMM)')
+    # split mode: conv1 + bn1 + relu + maxpool are ONE launch (csrc/stem.hip) and the
+    # stem_tail region is empty; the fp32 mode keeps the separate launches
+    mfma('encoder.stem', ['enc_stem'],
+         'conv1 7x7/2 + bn1 + relu + maxpool 3x3/2 as one launch (split mode; raw '
+         'conv1 rows written only inside the mask bounding box) / conv1 alone as '
+         'implicit GEMM (fp32 mode)')
     hbm('encoder.stem_tail', 'enc_stem_tail',
-        'bn1 + relu + maxpool 3x3/2 (112^2x64 fp32 read, 56^2x64 written)',
-        (112 * 112 * 64 + 56 * 56 * 64) * 4)
+        'bn1 + relu + maxpool 3x3/2 (112^2x64 fp32 read, 56^2x64 written; fp32 mode '
+        'only)', (112 * 112 * 64 + 56 * 56 * 64) * 4)
     for i in range(1, 5):
         mfma(f'encoder.layer{i}', [f'enc_layer{i}'],
-             f'torchvision layer{i} convolutions (implicit GEMM)')
+             f'torchvision layer{i} convolutions (implicit GEMM; split mode: chained '
+             f'expand -> reduce launches and register-resident 3x3 weights in layer1)'
+             if i < 3 else f'torchvision layer{i} convolutions (implicit GEMM)')
     hbm('encoder.pool', 'enc_pool',
         'mask-weighted pooling of the five taps (only pixels under the mask '
         'are read)', pool_bytes_img + 3904 * 4)
@@ -695,7 +702,7 @@ def main():
         pool_bytes = pooled_bytes_per_image(masks[:args.chunk])
         result['roofline'] = {
             'bound': 'mfma',
-            'kernel': ('igemm_split16_kernel / igemm_kernel<SPLIT> '
+            'kernel': ('igemm_split16_kernel (+ chain / stem / conv3 kernels of the front) '
                        '(v_mfma_f32_32x32x16_f16, 3 per product)' if split else
                        'igemm_kernel (v_mfma_f32_32x32x2_f32)'),
             'achieved': achieved,

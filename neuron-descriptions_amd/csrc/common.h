@@ -99,6 +99,8 @@ struct GemmArgs {
                       // experiments: 1 / 2 the round-1 256x128x3 / 128x128x2 kernels, 3 / 4 / 5
                       // split16 256x256x4 / 256x128x3 / 128x256x3, 6 / 10 N <= 64 on / off the
                       // 64x64-wave-tile split16 kernel, 8 the LDS-strip 3x3 kernel
+  int stagger;        // experiments build: half of the first-round workgroups of an expand conv
+                      // start this many microseconds late (MILAN_STAGGER)
   float* C2;          // EPI_LSTM: new cell state
   float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
 };

@@ -669,6 +669,15 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+#if MILAN_EXPERIMENTS
+  // phase stagger: every second first-round workgroup of an XCD starts late, so that half
+  // of the CUs are in their (HBM-bound) epilogue while the other half multiplies
+  if (g.stagger > 0 && blockIdx.x < (NT >= 512 ? 256 : 512) && ((blockIdx.x >> 3) & 1)) {
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    while (wall_clock64() - t0 < (unsigned long long)g.stagger * 100ull)
+      __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   // loader: NT threads cover NT/4 rows x 4 chunks per pass
   const int lrow = tid >> 2;                        // 0..LROWS-1
   const int kc = (tid & 3) ^ ((tid >> 4) & 3);      // (row>>2)&3 == (tid>>4)&3
@@ -1467,6 +1476,12 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("MILAN_ABLATE"); dbg = e ? atoi(e) : 0; }
     g.debug = dbg;  // 1: skip MFMA phase, 2: skip DMA (timing experiments only)
+#if MILAN_EXPERIMENTS
+    static int stg = -1;
+    if (stg < 0) { const char* e = getenv("MILAN_STAGGER"); stg = e ? atoi(e) : 0; }
+    // the expand convs (residual / two-source, epilogue-heavy launches)
+    g.stagger = (g.out_split && g.N >= 256 && g.KH == 1 && g.H > 1 && (g.aux || g.A2)) ? stg : 0;
+#endif
   }
   // pick the epilogue form
   if (g.epilogue == EPI_LSTM) {

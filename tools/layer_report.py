@@ -3,7 +3,9 @@
 usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3] [fused_ds=0|1] [chain=0|1]
 chain=1 (round 3): a bottleneck's expand conv c3 and the next bottleneck's reduce conv
 c1 are ONE launch (csrc/chain.hip) wherever the next block has no downsample branch and
-the stage is layer1..3; such pairs are reported as `lX.x.c3>c1`.
+the stage is layer1..3; such pairs are reported as `lX.x.c3>c1`.  The fused stem
+(csrc/stem.hip, one launch where the implicit-GEMM conv1 was) and layer1's conv3.hip
+launches take the places of the launches they replace.
 Maps the igemm dispatches of one hot-path pass onto the ResNet-101 layer list
 (launch order is deterministic) and prints time / algorithmic TFLOP/s per
 layer group, then the decoder+LM GEMM total.
@@ -23,6 +25,7 @@ def main():
     rows = db.execute(
         "select name, start, end-start, grid_x from kernels where name like "
         "'%igemm%' or name like '%conv3x3%' or name like '%chain_kernel%' "
+        "or name like '%stem_fused%' or name like '%conv3_p64%' "
         "order by start").fetchall()
     per = len(rows) // passes
     rows = rows[per * (passes - 1):]
@@ -85,7 +88,8 @@ def main():
     others = db.execute(
         "select name, count(*), sum(end-start) from kernels where name not "
         "like '%igemm%' and name not like '%conv3x3%' and name not like "
-        "'%chain_kernel%' group by name "
+        "'%chain_kernel%' and name not like '%stem_fused%' and name not like "
+        "'%conv3_p64%' group by name "
         "order by 3 desc limit 12").fetchall()
     for nm, c, t in others:
         print(f'  {nm[:60]:60s} x{c:5d} {t/1e6/passes:8.2f} ms/pass')

@@ -15,7 +15,7 @@ print([t for t in tabs if 'pmc' in t.lower() or 'counter' in t.lower()])
 try:
     q="select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name order by 1,2"
     for r in db.execute(q):
-        if 'igemm' in r[0] or 'chain_kernel' in r[0]: print(r[0][:70], r[1], r[2], r[3])
+        if any(k in r[0] for k in ('igemm', 'chain_kernel', 'stem_fused', 'conv3_p64')): print(r[0][:70], r[1], r[2], r[3])
 except Exception as e:
     print('ERR', e)
     for t in tabs: 

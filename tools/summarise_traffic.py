@@ -19,7 +19,7 @@ def read(counter):
     table = {}
     for line in open(f'{src}/traffic_{counter}.txt'):
         name, ctr, launches, total = line.rsplit(None, 3)
-        if ctr != counter or ('igemm' not in name and 'chain_kernel' not in name):
+        if ctr != counter or not any(k in name for k in ('igemm', 'chain_kernel', 'stem_fused', 'conv3_p64')):
             continue
         key = re.sub(r'^void_milan::|\(.*$|_', '', name)
         table[key] = (int(launches), float(total))
