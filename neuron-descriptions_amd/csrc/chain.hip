@@ -89,7 +89,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // KD: channels of the second expand source (0 = none; then there is a residual).
 // XACC: the reduce product keeps its cross terms (hl + lh) in a second accumulator,
 // like igemm_kernel<SPLIT> does for N <= 64 layers -- same bits as that kernel.
-template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false>
+// NR: output channels of the reduce conv: P inside a stage, 2 P when the next block opens
+// the next stage (its conv1 still runs at this stage's resolution).
+template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P>
 __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
     }
   };
   if constexpr (PROF) tlast = __builtin_readcyclecounter();
-  constexpr int N3 = 4 * P, N1 = P;
+  constexpr int N3 = 4 * P, N1 = NR;
   constexpr int K3 = P + KD;        // K of the expand product
   constexpr int KS3 = K3 / 16;      // its k-steps (16 channels)
   constexpr int NSLAB = N3 / 64;    // 64-channel slabs of the expand output
@@ -509,16 +511,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
 // runs while its partner waits, and both waves' MFMAs share one pipe.  Removed from the
 // library; numbers in DESIGN.md section 5.)
 
-bool chain_supported(int P, int KD) {
+bool chain_supported(int P, int KD, int NR) {
+  if (NR == 2 * P) return KD == 0 && P == 64;  // stage boundary layer1 -> layer2
+  if (NR != P) return false;
   if (KD == 0) return P == 64 || P == 128 || P == 256;
   return P == 64 && KD == 64;
 }
 
-template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false>
+template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P>
 static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * (size_t)((RES_LDS ? 7 : 4) * kTileFloats +
                                               NW * 32 * kSRow + (RES_LDS ? 4 * P : 0));
-  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF>;
+  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF, NR>;
   static bool attr_set = false;
   if (!attr_set) {
     MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -534,21 +538,24 @@ static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
 }
 
 int launch_chain(const ChainArgs& a, hipStream_t s) {
-  MILAN_REQUIRE(chain_supported(a.P, a.KD) && a.M > 0, MILAN_ERR_SHAPE,
-                "chain: unsupported planes %d (+%d)", a.P, a.KD);
+  const int NR = a.NR ? a.NR : a.P;
+  MILAN_REQUIRE(chain_supported(a.P, a.KD, NR) && a.M > 0, MILAN_ERR_SHAPE,
+                "chain: unsupported planes %d (+%d) -> %d", a.P, a.KD, NR);
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   MILAN_REQUIRE(al(a.T2) && al(a.W3) && al(a.bias3) && al(a.X) && al(a.W1) &&
                     al(a.bias1) && al(a.T1) &&
                     (a.KD ? (a.A2 && al(a.A2) && !a.R) : (a.R && al(a.R))),
                 MILAN_ERR_SHAPE, "chain: operands must be 16-byte aligned");
-  const double M = a.M, P = a.P, K3 = a.P + a.KD;
+  const double M = a.M, P = a.P, K3 = a.P + a.KD, R1 = NR;
   void* rec = gemm_profile_begin(
-      2.0 * M * (4 * P) * (K3 + P),
-      4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * P + 4 * P * (K3 + P)), s);
+      2.0 * M * (4 * P) * (K3 + R1),
+      4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * R1 + 4 * P * (K3 + R1)), s);
   int r;
   if (a.P == 256 && a.prof) r = launch_chain_cfg<256, 4, true, 0, false, true>(a, s);
   else if (a.P == 256) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
   else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);
+  // the 128-channel reduce conv runs on the single-accumulator kernel when unfused
+  else if (NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128>(a, s);
   else if (a.KD == 0) r = launch_chain_cfg<64, 8, false, 0, true>(a, s);
   else r = launch_chain_cfg<64, 8, false, 64, true>(a, s);
   gemm_profile_end(rec, s);

@@ -128,16 +128,17 @@ struct ChainArgs {
   const float* bias3;  // [4P]
   const float* R;      // [M][4P] residual
   float* X;            // [M][4P]
-  const float* W1;     // [P][4P] split weights (scaled)
-  const float* bias1;  // [P]
-  float* T1;           // [M][P]
+  const float* W1;     // [NR][4P] split weights (scaled)
+  const float* bias1;  // [NR]
+  float* T1;           // [M][NR]
   int M, P;
   const float* A2;     // [M][KD] or nullptr
   int KD;              // channels of A2 (0 without)
   float scale3, scale1;  // 1 / weight scale of W3, W1
   long long* prof;       // timing experiments: per-workgroup phase cycles (8 per WG)
+  int NR;                // output channels of the reduce conv (0 = P; 2 P at a stage boundary)
 };
-bool chain_supported(int P, int KD);
+bool chain_supported(int P, int KD, int NR = 0);
 int launch_chain(const ChainArgs& a, hipStream_t s);
 // ---- fused split-f16 stem (stem.hip): conv1 7x7/2 + bn1 + ReLU + maxpool 3x3/2 ----
 struct StemArgs {

@@ -1014,11 +1014,12 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   // 4. bottleneck stages; tap after each stage
   float *x = pl.x0, *y = pl.x1;
   int h = pl.hp, w = pl.wp, col = wd;
+  // t1_ready: pl.t1 already holds this block's c1 output -- the previous block's
+  // expand conv and this block's reduce conv ran as one launch (chain.hip); survives
+  // the stage boundary (the last block of layer1 chains into layer2.0's conv1)
+  bool t1_ready = false;
   for (int li = 0; li < 4; ++li) {
     stage.emplace(MILAN_STAGE_ENC_LAYER1 + li, s);
-    // t1_ready: pl.t1 already holds this block's c1 output -- the previous block's
-    // expand conv and this block's reduce conv ran as one launch (chain.hip)
-    bool t1_ready = false;
     const std::vector<Bottleneck>& blocks = c->blocks[li];
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
       const Bottleneck& b = blocks[bi];
@@ -1063,24 +1064,32 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       const float* identity = x;
       // Expand conv of this block + reduce conv of the next one in ONE launch: the
       // 4P-channel block output is written once and not read back by the next c1.
-      if (split && bi + 1 < blocks.size() &&
+      // the next block: in this stage, or the first one of the next stage (its conv1
+      // is a 1x1 / stride 1 over this stage's output; the stride sits on its conv2)
+      const bool last_of_stage = bi + 1 == blocks.size();
+      const Bottleneck* nbp = !last_of_stage ? &blocks[bi + 1]
+                              : (li + 1 < 4 && !c->blocks[li + 1].empty())
+                                    ? &c->blocks[li + 1][0] : nullptr;
+      if (split && nbp != nullptr &&
           (c->fusion & (b.c3.cin >= 256 ? MILAN_FUSE_CHAIN_WIDE : MILAN_FUSE_CHAIN))) {
-        const Bottleneck& nb = blocks[bi + 1];
+        const Bottleneck& nb = *nbp;
         const int P = b.c3.cin;
-        const bool shapes = !nb.basic && !nb.has_down && nb.c1.ws && b.c3.ws &&
-                            b.c3.kh == 1 && b.c3.kw == 1 && b.c3.stride == 1 &&
+        const int NR = last_of_stage ? 2 * P : P;
+        const bool shapes = !nb.basic && nb.has_down == last_of_stage && nb.c1.ws &&
+                            b.c3.ws && b.c3.kh == 1 && b.c3.kw == 1 && b.c3.stride == 1 &&
                             b.c3.K == b.c3.Kp && b.c3.cout == 4 * P &&
                             nb.c1.kh == 1 && nb.c1.kw == 1 && nb.c1.stride == 1 &&
-                            nb.c1.cin == 4 * P && nb.c1.cout == P &&
+                            nb.c1.cin == 4 * P && nb.c1.cout == NR &&
                             nb.c1.K == nb.c1.Kp && b.c3.bias && nb.c1.bias;
-        const bool plain = shapes && !b.has_down && chain_supported(P, 0);
+        const bool plain = shapes && !b.has_down && chain_supported(P, 0, NR);
         const bool with_ds = shapes && b.has_down && b.c3d.ws && b.down.kh == 1 &&
                              b.down.kw == 1 && b.down.stride == 1 && h2 == h &&
-                             w2 == w && chain_supported(P, b.down.cin);
+                             w2 == w && chain_supported(P, b.down.cin, NR);
         if (plain || with_ds) {
           ChainArgs ca{};
           ca.T2 = pl.t2; ca.X = y; ca.W1 = nb.c1.ws; ca.bias1 = nb.c1.bias;
           ca.T1 = pl.t1; ca.M = n * h2 * w2; ca.P = P; ca.scale1 = nb.c1.ws_inv;
+          ca.NR = NR;
           if (plain) {
             ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias; ca.R = x; ca.scale3 = b.c3.ws_inv;
           } else {

@@ -649,7 +649,7 @@ __device__ __forceinline__ int xcd_tile(int b, int T) {
 
 template <int BM, int BN, int STAGES, int SHAPE, int TMW = 4>
 __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
-                                             int tile_n) {
+                                             int tile_n, int tid_in = -1) {
   constexpr int BK = 16;
   constexpr int TM = TMW, TN = 2;             // wave tile (TM*32) x 64: 128 x 64,
                                               // or 64 x 64 for the N = 64 layers
@@ -664,7 +664,7 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   float* As = smem;                        // [STAGES][BM*16]
   float* Bs = smem + STAGES * BM * BK;     // [STAGES][BN*16]
 
-  const int tid = threadIdx.x;
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -894,9 +894,20 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
 template <int BM, int BN, int STAGES, int SHAPE>
 __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_kernel(
     GemmArgs g, int tiles_m, int tiles_n) {
-  const int tile = xcd_tile(blockIdx.x, tiles_m * tiles_n);
-  const int tile_m = tile / tiles_n;
-  split16_tile<BM, BN, STAGES, SHAPE>(g, tile_m, tile - tile_m * tiles_n);
+  // one tile per workgroup (gridDim.x == tiles), or persistent workgroups walking
+  // tiles q = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8: q stays on its XCD)
+  const int T = tiles_m * tiles_n;
+  for (int q = blockIdx.x; q < T; q += gridDim.x) {
+    const int tile = xcd_tile(q, T);
+    const int tile_m = tile / tiles_n;
+    // opaque per iteration: nothing derived from the thread index is kept live across
+    // tiles (the 256 x 256 kernel has no registers to spare)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    split16_tile<BM, BN, STAGES, SHAPE>(g, tile_m, tile - tile_m * tiles_n, tid);
+    // the epilogue's staging reads are done before the next tile's DMA lands there
+    __builtin_amdgcn_s_barrier();
+  }
 }
 
 // The same pipeline with 64 x 64 wave tiles (4 waves per 256 x 64 block, two
@@ -1373,8 +1384,16 @@ static int launch_split16_impl(const GemmArgs& g, hipStream_t s) {
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, g, tiles_m,
-                     tiles_n);
+  int grid = tiles_m * tiles_n;
+#if MILAN_EXPERIMENTS
+  // MILAN_PERSIST=<workgroups>: persistent grid (a multiple of 8)
+  static int persist = -1;
+  if (persist < 0) { const char* e = getenv("MILAN_PERSIST"); persist = e ? atoi(e) : 0; }
+  // (4-wave tiles run two workgroups per CU)
+  const int pgrid = persist / 8 * 8 * (NT == 256 ? 2 : 1);
+  if (persist >= 8 && grid > pgrid) grid = pgrid;
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, g, tiles_m, tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }

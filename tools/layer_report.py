@@ -40,9 +40,9 @@ def main():
 
     conv('stem', 224, 3, 64, 7, 2)
     h, inp = 56, 64
+    chained_c1 = False  # this block's c1 ran inside the previous block's launch
     for li, nb in enumerate((3, 4, 23, 3)):
         pl = 64 * 2**li
-        chained_c1 = False  # this block's c1 ran inside the previous block's launch
         for bi in range(nb):
             s = 2 if (bi == 0 and li > 0) else 1
             if not chained_c1:
@@ -50,15 +50,21 @@ def main():
             h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
             # chain.hip: planes <= 256, a next block in the stage; block 0 (two-source
             # expand) only where its downsample has stride 1 (layer1)
-            chained_c1 = (chain and pl <= (256 if wide else 128) and bi + 1 < nb and
-                          (bi > 0 or (fused and li == 0)))
+            # ... or, for planes 64, the first block of the next stage (its c1 has 2 x
+            # the planes and runs at this stage's resolution)
+            boundary = chain and bi + 1 == nb and pl == 64
+            chained_c1 = boundary or (
+                chain and pl <= (256 if wide else 128) and bi + 1 < nb and
+                (bi > 0 or (fused and li == 0)))
             tag = f'l{li+1}.{bi}.'
             if chained_c1:
                 m = n * h2 * h2
                 k3 = pl + (inp if bi == 0 else 0)
-                name = tag + ('c3+ds>c1' if bi == 0 else 'c3>c1')
-                layers.append((name, m, pl * 4, k3 + pl,
-                               2 * m * pl * 4 * k3 + 2 * m * pl * pl * 4))
+                nr = 2 * pl if boundary else pl
+                name = tag + ('c3+ds>c1' if bi == 0 else
+                              f'c3>l{li+2}.0.c1' if boundary else 'c3>c1')
+                layers.append((name, m, pl * 4, k3 + nr,
+                               2 * m * pl * 4 * k3 + 2 * m * nr * pl * 4))
             elif bi == 0 and not fused:
                 conv(tag + 'ds', h, inp, pl * 4, 1, s)
                 conv(tag + 'c3', h2, pl, pl * 4, 1, 1)
