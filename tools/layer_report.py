@@ -15,20 +15,13 @@ import sqlite3
 import sys
 
 
-def main():
-    db = sqlite3.connect(sys.argv[1])
-    n = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
-    passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    fused = len(sys.argv) > 4 and sys.argv[4] == '1'  # split mode: ds folded into c3
-    chain = len(sys.argv) > 5 and sys.argv[5] in ("1", "2")
-    wide = len(sys.argv) > 5 and sys.argv[5] == "2"  # layer3 chains on too
-    rows = db.execute(
-        "select name, start, end-start, grid_x from kernels where name like "
-        "'%igemm%' or name like '%conv3x3%' or name like '%chain_kernel%' "
-        "or name like '%stem_fused%' or name like '%conv3_p64%' "
-        "order by start").fetchall()
-    per = len(rows) // passes
-    rows = rows[per * (passes - 1):]
+GEMM_LIKE = ("name like '%igemm%' or name like '%conv3x3%' or name like '%chain_kernel%' "
+             "or name like '%stem_fused%' or name like '%conv3_p64%'")
+
+
+def build_layers(n, fused, chain, wide):
+    """(name, M, N, K, flops) of the encoder's GEMM-class launches of one pass of n
+    images, in launch order (ResNet-101, split-f16 mode)."""
     layers = []
 
     def conv(name, h, cin, cout, k, s, extra_k=0):
@@ -73,10 +66,30 @@ def main():
             else:
                 conv(tag + 'c3', h2, pl, pl * 4, 1, 1)
             h, inp = h2, pl * 4
+    return layers
+
+
+def group_key(name):
+    return name if '.0.' in name.split('>')[0] or name == 'stem' else re.sub(
+        r'\.\d+\.', '.x.', name, count=1)
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
+    passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    fused = len(sys.argv) > 4 and sys.argv[4] == '1'  # split mode: ds folded into c3
+    chain = len(sys.argv) > 5 and sys.argv[5] in ("1", "2")
+    wide = len(sys.argv) > 5 and sys.argv[5] == "2"  # layer3 chains on too
+    rows = db.execute(
+        "select name, start, end-start, grid_x from kernels where " + GEMM_LIKE +
+        " order by start").fetchall()
+    per = len(rows) // passes
+    rows = rows[per * (passes - 1):]
+    layers = build_layers(n, fused, chain, wide)
     agg, tot_t, tot_f = {}, 0, 0
     for (name, m, nn, k, fl), (_, _, du, _) in zip(layers, rows):
-        key = name if '.0.' in name or name == 'stem' else re.sub(
-            r'\.\d+\.', '.x.', name)
+        key = group_key(name)
         a = agg.setdefault(key, [0, 0, 0, m, nn, k])
         a[0] += fl
         a[1] += du
@@ -92,11 +105,8 @@ def main():
     print('decoder+lm GEMM launches', len(dec), 'time ms',
           sum(r[2] for r in dec) / 1e6)
     others = db.execute(
-        "select name, count(*), sum(end-start) from kernels where name not "
-        "like '%igemm%' and name not like '%conv3x3%' and name not like "
-        "'%chain_kernel%' and name not like '%stem_fused%' and name not like "
-        "'%conv3_p64%' group by name "
-        "order by 3 desc limit 12").fetchall()
+        "select name, count(*), sum(end-start) from kernels where not (" + GEMM_LIKE +
+        ") group by name order by 3 desc limit 12").fetchall()
     for nm, c, t in others:
         print(f'  {nm[:60]:60s} x{c:5d} {t/1e6/passes:8.2f} ms/pass')
 

@@ -14,13 +14,17 @@ tables = [r[0] for r in db.execute("select name from sqlite_master where type in
 # counters_collection view: one row per (dispatch, counter)
 cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
 print('#', cols)
-q = "select dispatch_id, kernel_name, sum(value) from counters_collection where kernel_name like '%igemm%' group by dispatch_id, kernel_name order by dispatch_id"
+q = ("select dispatch_id, kernel_name, sum(value) from counters_collection where kernel_name like '%igemm%' "
+     "or kernel_name like '%chain_kernel%' or kernel_name like '%stem_fused%' or kernel_name like '%conv3_p64%' "
+     "group by dispatch_id, kernel_name order by dispatch_id")
 for r in db.execute(q):
     print(r[0], r[1].split('(')[0].replace(' ', ''), r[2])
 PY
 done
 python - <<'PY'
-import re
+import sys
+sys.path.insert(0, 'tools')
+from layer_report import build_layers, group_key
 def load(c):
     rows = []
     for line in open(f'gpurun_out/pmc_dispatch_{c}.txt'):
@@ -30,29 +34,12 @@ def load(c):
     return rows
 F, W = load('FETCH_SIZE'), load('WRITE_SIZE')
 n = 3840
-layers = []
-def conv(name, h, cin, cout, k, s, extra=0):
-    ho = (h + 2*(k//2) - k)//s + 1
-    m = n*ho*ho
-    layers.append((name, m, cout, k*k*cin + extra, cin, ho))
-    return ho
-conv('stem', 224, 3, 64, 7, 2)
-h, inp = 56, 64
-for li, nb in enumerate((3,4,23,3)):
-    pl = 64*2**li
-    for bi in range(nb):
-        s = 2 if (bi == 0 and li > 0) else 1
-        conv(f'l{li+1}.{bi}.c1', h, inp, pl, 1, 1)
-        h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
-        if bi == 0: conv(f'l{li+1}.{bi}.c3+ds', h2, pl, pl*4, 1, 1, extra=inp)
-        else: conv(f'l{li+1}.{bi}.c3', h2, pl, pl*4, 1, 1)
-        h, inp = h2, pl*4
+layers = build_layers(n, True, True, False)  # split mode: folded downsamples, layer1/2 chains
 agg = {}
-for (name, m, nn, k, cin, ho), f, w in zip(layers, F, W):
-    key = name if '.0.' in name or name == 'stem' else re.sub(r'\.\d+\.', '.x.', name)
-    a = agg.setdefault(key, [0, 0.0, 0.0, m, nn, k])
+for (name, m, nn, k, fl), f, w in zip(layers, F, W):
+    a = agg.setdefault(group_key(name), [0, 0.0, 0.0, m, nn, k, f[1][:40]])
     a[0] += 1; a[1] += f[2]; a[2] += w[2]
-print('layer        x   fetch GB/launch (x2 corrected)   write GB/launch   algorithmic out GB')
-for key, (c, f, w, m, nn, k) in agg.items():
-    print(f'{key:10s} x{c:2d}  fetch {2*f*1024/c/1e9:7.3f}  write {w*1024/c/1e9:7.3f}   out {m*nn*4/1e9:6.3f}  in {m*k*4/1e9 if "c2" not in key else m*k*4/9/1e9:6.3f}')
+print('layer              x   fetch GB/launch (x2 corrected)   write GB/launch   M x N x 4 B (GB)   kernel')
+for key, (c, f, w, m, nn, k, kern) in agg.items():
+    print(f'{key:18s} x{c:2d}  fetch {2*f*1024/c/1e9:7.3f}  write {w*1024/c/1e9:7.3f}   out {m*nn*4/1e9:6.3f}   {kern}')
 PY
