@@ -672,10 +672,11 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
 #if MILAN_EXPERIMENTS
   // phase stagger: every second first-round workgroup of an XCD starts late, so that half
   // of the CUs are in their (HBM-bound) epilogue while the other half multiplies
-  if (g.stagger > 0 && blockIdx.x < (NT >= 512 ? 256 : 512) && ((blockIdx.x >> 3) & 1)) {
+  if (g.stagger > 0 && blockIdx.x < (NT >= 512 ? 256 : 512) && ((blockIdx.x >> 3) & 3)) {
+    // four phases per XCD: 0, 1, 2, 3 x stagger microseconds
     const unsigned long long t0 = wall_clock64();  // 100 MHz
-    while (wall_clock64() - t0 < (unsigned long long)g.stagger * 100ull)
-      __builtin_amdgcn_s_sleep(8);
+    const unsigned long long dt = (unsigned long long)g.stagger * 100ull * ((blockIdx.x >> 3) & 3);
+    while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
   }
 #endif
   // loader: NT threads cover NT/4 rows x 4 chunks per pass
@@ -1499,7 +1500,9 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
     static int stg = -1;
     if (stg < 0) { const char* e = getenv("MILAN_STAGGER"); stg = e ? atoi(e) : 0; }
     // the expand convs (residual / two-source, epilogue-heavy launches)
-    g.stagger = (g.out_split && g.N >= 256 && g.KH == 1 && g.H > 1 && (g.aux || g.A2)) ? stg : 0;
+    static int stg_all = -1;
+    if (stg_all < 0) { const char* e = getenv("MILAN_STAGGER_ALL"); stg_all = e ? atoi(e) : 0; }
+    g.stagger = (stg_all || (g.out_split && g.N >= 256 && g.KH == 1 && g.H > 1 && (g.aux || g.A2))) ? stg : 0;
 #endif
   }
   // pick the epilogue form
