@@ -101,6 +101,9 @@ struct GemmArgs {
                       // 64x64-wave-tile split16 kernel, 8 the LDS-strip 3x3 kernel
   int stagger;        // experiments build: half of the first-round workgroups of an expand conv
                       // start this many microseconds late (MILAN_STAGGER)
+  int chunk_major;    // experiments build, split16 kernels, k x k convs: k runs (16-channel chunk,
+                      // tap) with the taps INNER -- the KH*KW pieces of a pixel are requested in
+                      // consecutive k-tiles and hit L2 -- and W is packed to match (ConvW::ws3)
   float* C2;          // EPI_LSTM: new cell state
   float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
 };
@@ -230,7 +233,7 @@ __host__ __device__ inline int lstm_interleaved_row(int gate, int u) {
 struct ConvW {
   float* w = nullptr;     // [Cout][Kp]
   float* ws = nullptr;    // same, split-f16 format, scaled by 1/ws_inv
-  float* ws3 = nullptr;   // 3x3 only: ws re-ordered chunk-major (gemm.hip)
+  float* ws3 = nullptr;   // 3x3 only, experiments build: ws re-ordered chunk-major (gemm.hip)
   float ws_inv = 1.f;     // exact power of two
   float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
   int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;

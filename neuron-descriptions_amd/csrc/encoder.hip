@@ -147,10 +147,10 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
     MILAN_TRY(make_split_weight(c, out->w, out->cout, out->Kp, &out->ws,
                                 &out->ws_inv, s));
 #if MILAN_EXPERIMENTS
-    if (out->ws && out->kh == 3 && out->kw == 3 && out->stride == 1 &&
-        out->pad == 1 && out->Kp == out->K) {
-      // chunk-major copy for the LDS-strip 3x3 kernel: 32-byte groups of 8
-      // channels move from [tap][Cin/8] to [Cin/16][tap][2]
+    if (out->ws && out->kh == 3 && out->kw == 3 && out->Kp == out->K &&
+        out->cin % 16 == 0) {
+      // chunk-major copy for the LDS-strip 3x3 kernel and MILAN_TAPS_INNER: 32-byte groups
+      // of 8 channels move from [tap][Cin/8] to [Cin/16][tap][2]
       MILAN_TRY(dev_alloc(c, (void**)&out->ws3,
                           sizeof(float) * (size_t)out->cout * out->Kp));
       MILAN_TRY(make_chunk_major(out->ws, out->cout, out->cin, out->ws3, s));
@@ -1050,6 +1050,19 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       t1_ready = false;
       GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU,
                               nullptr, c->zero, &h2, &w2, split);
+#if MILAN_EXPERIMENTS
+      {
+        // MILAN_TAPS_INNER=1: 3x3 convs of layer2..4 with the nine taps of a 16-channel
+        // chunk in consecutive k-tiles (each pixel crosses the fabric once, not once per
+        // tap; NOT the same bits; measured: no gain, profiles/r3_experiments.txt L)
+        static const bool taps_inner = getenv("MILAN_TAPS_INNER") && atoi(getenv("MILAN_TAPS_INNER"));
+        if (split && taps_inner && b.c2.ws3 && b.c2.cin >= 128 && b.c2.cout > 64) {
+          g2.W = b.c2.ws3;
+          g2.chunk_major = 1;
+          g2.W3 = nullptr;  // not the LDS-strip kernel
+        }
+      }
+#endif
       if (split && (c->fusion & MILAN_FUSE_CONV3) && b.c2.K == b.c2.Kp &&
           conv3_p64_supported(b.c2.cin, b.c2.cout, b.c2.kh, b.c2.kw, b.c2.stride,
                               b.c2.pad)) {

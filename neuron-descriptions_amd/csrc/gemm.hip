@@ -726,10 +726,20 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   auto advance_tap = [&]() {
     if (is_kt + 1 >= nk_total) return;  // dummy tiles re-read the last tile
     ++is_kt;
-    is_cin0 += BK;
-    if (is_cin0 >= g.Cin) {
-      is_cin0 = 0;
-      if (++is_kw == g.KW) { is_kw = 0; ++is_kh; }
+    if constexpr (SHAPE == 2) {
+      // chunk-major k order (GemmArgs::chunk_major): the KH x KW taps of a 16-channel chunk
+      // in consecutive k-tiles.  A compile-time variant: the extra scalar work of a run-time
+      // choice in this loop cost 6 % on every layer.
+      if (++is_kw == g.KW) {
+        is_kw = 0;
+        if (++is_kh == g.KH) { is_kh = 0; is_cin0 += BK; }
+      }
+    } else {
+      is_cin0 += BK;
+      if (is_cin0 >= g.Cin) {
+        is_cin0 = 0;
+        if (++is_kw == g.KW) { is_kw = 0; ++is_kh; }
+      }
     }
   };
   // Past the end of K the loader keeps re-reading the last k-tile into ring
@@ -1427,6 +1437,9 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
   if (shape < 0) { const char* e = getenv("MILAN_SCHED"); shape = e ? atoi(e) : 0; }
   if (shape == 1) return launch_split16_impl<BM, BN, STAGES, 1>(g, s);
 #endif
+#if MILAN_EXPERIMENTS
+  if (g.chunk_major) return launch_split16_impl<BM, BN, STAGES, 2>(g, s);
+#endif
   return launch_split16_impl<BM, BN, STAGES, 0>(g, s);
 }
 
@@ -1561,6 +1574,8 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
         (g.tile_hint == 6 || (g.tile_hint == 0 && g.KH * g.KW > 1)))
       return launch_split16_tm2<256, 64, 3>(g, s);
     if (g.N <= 64) return launch_cfg<256, 64, 2, true, true>(g, s);
+    MILAN_REQUIRE(!g.chunk_major || (MILAN_EXPERIMENTS && g.tile_hint == 0 && !g.A2 && g.Cin % 16 == 0),
+                  MILAN_ERR_SHAPE, "gemm: chunk-major k order: experiments build, split16 kernels");
 #if MILAN_EXPERIMENTS
     // 3x3 / stride 1 with the chunk-major weight copy: input strip in LDS
     if (g.W3 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && !g.A2 &&
