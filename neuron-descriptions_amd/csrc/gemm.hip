@@ -726,6 +726,7 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   auto advance_tap = [&]() {
     if (is_kt + 1 >= nk_total) return;  // dummy tiles re-read the last tile
     ++is_kt;
+    if constexpr (SHAPE == 3) return;
     if constexpr (SHAPE == 2) {
       // chunk-major k order (GemmArgs::chunk_major): the KH x KW taps of a 16-channel chunk
       // in consecutive k-tiles.  A compile-time variant: the extra scalar work of a run-time
@@ -755,6 +756,14 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
     if (abl_dma) { if (piece == LOADS - 1) advance_tap(); return; }
     if (piece < A_ITERS) {
       const int it = piece;
+      if constexpr (SHAPE == 3) {
+        // 1x1 / pad 0 / one source (most of the trunk, every Linear): the A row of a
+        // k-tile is base + 16 kt -- no tap arithmetic, no bounds test in the loop
+        float* adst = As + buf * (BM * BK) + wave * (16 * BK) + it * (LROWS * BK);
+        __builtin_amdgcn_global_load_lds(
+            (const GLOBAL_AS void*)(ra[it].base + is_kt * BK), (LDS_AS void*)adst, 16, 0, 0);
+        return;
+      }
       const long toff = ((long)is_kh * g.Wd + is_kw) * g.a_pix_stride + is_cin0;
       const int hi = ra[it].hi0 + is_kh, wi = ra[it].wi0 + is_kw;
       const bool inb = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.Wd;
@@ -1439,7 +1448,13 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
 #endif
 #if MILAN_EXPERIMENTS
   if (g.chunk_major) return launch_split16_impl<BM, BN, STAGES, 2>(g, s);
+  static int lin = -1;
+  if (lin < 0) { const char* e = getenv("MILAN_LINEAR_KERNEL"); lin = e ? atoi(e) : 1; }
+  if (!lin) return launch_split16_impl<BM, BN, STAGES, 0>(g, s);
 #endif
+  // 1x1 convolutions and Linear layers: the loop variant without tap arithmetic
+  if (g.KH == 1 && g.KW == 1 && g.pad == 0 && g.A2 == nullptr)
+    return launch_split16_impl<BM, BN, STAGES, 3>(g, s);
   return launch_split16_impl<BM, BN, STAGES, 0>(g, s);
 }
 

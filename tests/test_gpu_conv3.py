@@ -40,6 +40,7 @@ def ctx(dev):
     (2, 7, 9),        # 2 x 3: smaller than one tile
     (1, 1, 1),
     (40, 32, 32),     # many images, one partial tile each
+    (2, 320, 256),    # 80 x 64 at layer1: 10 x 5 tiles
 ])
 def test_conv3_is_bitwise_the_implicit_gemm(ctx, n, h, w):
     c, _ = ctx

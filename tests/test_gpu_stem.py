@@ -72,6 +72,7 @@ def _masks(kind, n, h, w, g):
     (3, 7, 9, 'random'),        # smaller than one tile, taps hang over every edge
     (2, 1, 1, 'none'),
     (17, 40, 40, 'rect'),
+    (2, 320, 256, 'rect'),      # larger than the benchmark geometry: 80 x 64 pooled
 ])
 def test_fused_stem_is_bitwise_the_three_launches(ctx, n, h, w, kind):
     c, _ = ctx
