@@ -16,7 +16,9 @@ from typing import Dict, Optional, Sequence
 
 import torch
 
-LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so'
+# MILAN_LIB=<path>: load another build of the library (A/B timing of compiler options)
+LIB_PATH = pathlib.Path(os.environ.get('MILAN_LIB') or
+                       pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so')
 
 GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _RERANK
 PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
