@@ -101,6 +101,7 @@ struct GemmArgs {
                       // 64x64-wave-tile split16 kernel, 8 the LDS-strip 3x3 kernel
   int stagger;        // experiments build: half of the first-round workgroups of an expand conv
                       // start this many microseconds late (MILAN_STAGGER)
+  long long* prof;    // experiments build: per-phase cycle sums over all workgroups (16 counters)
   int chunk_major;    // experiments build, split16 kernels, k x k convs: k runs (16-channel chunk,
                       // tap) with the taps INNER -- the KH*KW pieces of a pixel are requested in
                       // consecutive k-tiles and hit L2 -- and W is packed to match (ConvW::ws3)

@@ -867,13 +867,21 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
     }
   };
 
+#if MILAN_EXPERIMENTS
+  long long pt_last = g.prof ? clock64() : 0;
+#define G_STAMP(k) do { if (g.prof) { const long long t1 = clock64(); if (tid == 0) atomicAdd((unsigned long long*)g.prof + (k), (unsigned long long)(t1 - pt_last)); pt_last = t1; } } while (0)
+#else
+#define G_STAMP(k) do {} while (0)
+#endif
   // prologue: STAGES-1 tiles in flight (dummy ones if K is short), wait for
   // the first
   constexpr int AHEAD = STAGES - 1;
 #pragma unroll
   for (int t = 0; t < AHEAD; ++t) stage(t);
+  G_STAMP(0);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
   __builtin_amdgcn_s_barrier();
+  G_STAMP(1);
   int cur = 0;
   const int nk_run = (MILAN_ABLATE_BUILD && (g.debug & 4)) ? 0 : nk;  // epilogue only
   for (int kt = 0; kt < nk_run; ++kt) {
@@ -889,12 +897,14 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
     if (!abl_bar) __builtin_amdgcn_s_barrier();
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
+  G_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tiles
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * g.acc_scale;
+  G_STAMP(3);
 
   if (MILAN_ABLATE_BUILD && (g.debug & 8)) {  // main loop only
     float t = 0.f;
@@ -909,6 +919,7 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   }
   run_epilogue<TM, TN>(g, acc, smem, wave, lane, tile_m * BM + wm * WROWS,
                        tile_n * BN + wn * 64);
+  G_STAMP(4);
 }
 
 template <int BM, int BN, int STAGES, int SHAPE>
@@ -927,6 +938,226 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
     split16_tile<BM, BN, STAGES, SHAPE>(g, tile_m, tile - tile_m * tiles_n, tid);
     // the epilogue's staging reads are done before the next tile's DMA lands there
     __builtin_amdgcn_s_barrier();
+  }
+}
+
+// Persistent form of the 256 x 256 tile for 1x1 convolutions / Linear layers (one A
+// source, pad 0): a workgroup walks tiles q = blockIdx.x, + gridDim.x, ... and the ring
+// keeps rolling across them.  A tile of the one-launch-per-tile kernel starts with ~4 us
+// in which nothing multiplies (16 DMA instructions per wave to fill the ring, then the
+// HBM latency of the first A rows: 10 % of an expand-conv tile, in-kernel profile in
+// profiles/r3_experiments.txt P).  Here the last AHEAD iterations of a tile's main loop,
+// which have nothing left to fetch for it, fetch the A rows of the NEXT tile's first
+// AHEAD k-tiles instead -- they land under the epilogue -- and only the W rows (L2 hits)
+// are fetched after it.  The epilogue stages through the W half of the ring, which is
+// idle by then; the A half holds the prefetch.  Same instruction stream per k-tile, same
+// bits as igemm_split16_kernel.
+template <int STAGES>
+__global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
+                                                                    int tiles_m,
+                                                                    int tiles_n) {
+  constexpr int BM = 256, BN = 256, BK = 16, TM = 4, TN = 2;
+  constexpr int WROWS = TM * 32, WAVES_N = BN / 64, LROWS = 128;
+  constexpr int A_ITERS = BM / LROWS, B_ITERS = BN / LROWS, LOADS = A_ITERS + B_ITERS;
+  constexpr int AHEAD = STAGES - 1;
+  static_assert(STAGES == 5 && LOADS == TM, "one DMA piece per MFMA row group");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                        // [STAGES][BM*16]
+  float* Bs = smem + STAGES * BM * BK;     // [STAGES][BN*16]; the epilogue's staging
+  const int HoWo = g.Ho * g.Wo;
+  const int T = tiles_m * tiles_n;
+  const int nk = g.Kp / BK;  // >= AHEAD (launcher)
+
+  // A row pointers of a tile at the lane's 16-byte chunk (k-tile 0)
+  auto a_rows = [&](int tile_m, int lrow, int kc, const float* (&ra)[A_ITERS]) {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      int m = tile_m * BM + it * LROWS + lrow;
+      m = m < g.M ? m : g.M - 1;
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+      ra[it] = g.A + (long)img * g.a_img_stride +
+               ((long)(ho * g.stride) * g.Wd + wo * g.stride) * g.a_pix_stride + kc * 4;
+    }
+  };
+
+  int q = blockIdx.x;
+  if (q >= T) return;
+  int tile = xcd_tile(q, T);
+  int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  const float* ra[A_ITERS];
+  int cur = 0;  // ring slot of the tile's k-tile 0
+  {
+    const int tid0 = threadIdx.x;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    a_rows(tile_m, tid0 >> 2, (tid0 & 3) ^ ((tid0 >> 4) & 3), ra);
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t)
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it)
+        __builtin_amdgcn_global_load_lds(
+            (const GLOBAL_AS void*)(ra[it] + t * BK),
+            (LDS_AS void*)(As + t * (BM * BK) + wave0 * (16 * BK) + it * (LROWS * BK)), 16, 0, 0);
+  }
+
+  for (;;) {
+    // opaque per tile: nothing derived from the thread index stays live across the
+    // epilogue (the kernel has no registers to spare)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lrow = tid >> 2;
+    const int kc = (tid & 3) ^ ((tid >> 4) & 3);
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int aoff[TM], boff[TN], aswz[TM], bswz[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * WROWS + i * 32 + frow;
+      aoff[i] = row * BK;
+      aswz[i] = (row >> 2) & 3;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * 64 + j * 32 + frow;
+      boff[j] = row * BK;
+      bswz[j] = (row >> 2) & 3;
+    }
+    const float *ra_n[A_ITERS], *rb[B_ITERS];
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      int n = tile_n * BN + it * LROWS + lrow;
+      n = n < g.N ? n : g.N - 1;
+      rb[it] = g.W + (long)n * g.Kp + kc * 4;
+    }
+    auto issue_a = [&](const float* const (&rows)[A_ITERS], int it, int kt, int slot) {
+      __builtin_amdgcn_global_load_lds(
+          (const GLOBAL_AS void*)(rows[it] + kt * BK),
+          (LDS_AS void*)(As + slot * (BM * BK) + wave * (16 * BK) + it * (LROWS * BK)), 16, 0, 0);
+    };
+    auto issue_b = [&](int it, int kt, int slot) {
+      __builtin_amdgcn_global_load_lds(
+          (const GLOBAL_AS void*)(rb[it] + kt * BK),
+          (LDS_AS void*)(Bs + slot * (BN * BK) + wave * (16 * BK) + it * (LROWS * BK)), 16, 0, 0);
+    };
+    // the W rows of k-tiles 0 .. AHEAD-1 first (the A rows are in flight or landed); the
+    // next tile's addresses and the accumulator reset are computed while they fly
+    {
+      int slot = cur;
+#pragma unroll
+      for (int t = 0; t < AHEAD; ++t) {
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) issue_b(it, t, slot);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+      }
+    }
+    const bool has_next = q + (int)gridDim.x < T;
+    int ntile_m = tile_m, ntile_n = tile_n;
+    if (has_next) {
+      const int nt = xcd_tile(q + gridDim.x, T);
+      ntile_m = nt / tiles_n;
+      ntile_n = nt - ntile_m * tiles_n;
+    }
+    a_rows(ntile_m, lrow, kc, ra_n);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // MFMAs of the k-tile in ring slot `cur`; one DMA piece between the MFMA groups:
+    // STEADY the A and W rows of this tile's k-tile `kt_issue`; otherwise (tail) the A
+    // rows of the next tile's k-tile `kt_issue`, if there is a next tile
+    auto compute = [&](int cur_slot, int nxt_slot, int kt_issue, auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;
+      const float* Ab = As + cur_slot * (BM * BK);
+      const float* Bb = Bs + cur_slot * (BN * BK);
+      const int chi = 2 * fhalf, clo = chi + 1;
+      f32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] + ((chi ^ bswz[j]) << 2));
+        bl[j] = *reinterpret_cast<const f32x4*>(Bb + boff[j] + ((clo ^ bswz[j]) << 2));
+      }
+      ah[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((chi ^ aswz[0]) << 2));
+      al[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((clo ^ aswz[0]) << 2));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i + 1 < TM) {
+          ah[i + 1] = *reinterpret_cast<const f32x4*>(Ab + aoff[i + 1] +
+                                                      ((chi ^ aswz[i + 1]) << 2));
+          al[i + 1] = *reinterpret_cast<const f32x4*>(Ab + aoff[i + 1] +
+                                                      ((clo ^ aswz[i + 1]) << 2));
+        }
+        if constexpr (STEADY) {
+          if (i < A_ITERS) issue_a(ra, i, kt_issue, nxt_slot);
+          else issue_b(i - A_ITERS, kt_issue, nxt_slot);
+        } else {
+          if (i < A_ITERS && has_next) issue_a(ra_n, i, kt_issue, nxt_slot);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+              as_f16x8(ah[i]), as_f16x8(bl[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+              as_f16x8(al[i]), as_f16x8(bh[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+              as_f16x8(ah[i]), as_f16x8(bh[j]), acc[i][j], 0, 0, 0);
+        }
+      }
+    };
+    auto advance = [&]() { cur = cur + 1 == STAGES ? 0 : cur + 1; };
+    auto slot_ahead = [&]() { const int n = cur + AHEAD; return n >= STAGES ? n - STAGES : n; };
+
+    // steady state: k-tile kt + AHEAD of this tile is issued under k-tile kt
+    for (int kt = 0; kt + AHEAD < nk; ++kt) {
+      compute(cur, slot_ahead(), kt + AHEAD, std::true_type{});
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      advance();
+    }
+    // tail: the last AHEAD k-tiles.  Before k-tile (current + 1) starts it must have
+    // landed; what was issued after it -- the rest of this tile, the next tile's A rows
+    // -- may still fly (the last tile of a workgroup issues nothing and drains)
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) {
+      compute(cur, slot_ahead(), t, std::false_type{});
+      if (t + 1 < AHEAD) {
+        if (has_next) {
+          if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS + A_ITERS) : "memory");
+          else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + 2 * A_ITERS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * A_ITERS) : "memory");
+        } else {
+          if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+          else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      advance();
+    }
+    // every wave is done with the W half of the ring before it becomes staging
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * g.acc_scale;
+    run_epilogue<TM, TN>(g, acc, Bs, wave, lane, tile_m * BM + wm * WROWS,
+                         tile_n * BN + wn * 64);
+    if (!has_next) break;
+    // staging reads are done before the next tile's W rows land there
+    __builtin_amdgcn_s_barrier();
+    q += gridDim.x;
+    tile_m = ntile_m; tile_n = ntile_n;
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) ra[it] = ra_n[it];
+    // `cur` already points at the slot of the next tile's k-tile 0 (the ring kept rolling)
   }
 }
 
@@ -1453,8 +1684,41 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
   if (!lin) return launch_split16_impl<BM, BN, STAGES, 0>(g, s);
 #endif
   // 1x1 convolutions and Linear layers: the loop variant without tap arithmetic
-  if (g.KH == 1 && g.KW == 1 && g.pad == 0 && g.A2 == nullptr)
+  if (g.KH == 1 && g.KW == 1 && g.pad == 0 && g.A2 == nullptr) {
+    if constexpr (BM == 256 && BN == 256 && STAGES == 5) {
+      // more tiles than CUs: persistent workgroups, the next tile's A rows prefetched
+      // under the epilogue (igemm_split16_linp_kernel)
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        MILAN_CHECK_HIP(hipGetDevice(&dev));
+        MILAN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cus = cus < 8 ? 8 : cus / 8 * 8;
+      }
+      bool on = true;
+#if MILAN_EXPERIMENTS
+      static int plin = -1;
+      if (plin < 0) { const char* e = getenv("MILAN_PERSIST_LIN"); plin = e ? atoi(e) : 1; }
+      on = plin != 0;
+#endif
+      const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+      if (on && g.Kp / 16 >= STAGES - 1 && tiles_m * tiles_n > cus) {
+        const size_t lds = size_t(STAGES) * (BM + BN) * 16 * sizeof(float);
+        auto kern = igemm_split16_linp_kernel<STAGES>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          MILAN_CHECK_HIP(hipFuncSetAttribute(
+              reinterpret_cast<const void*>(kern),
+              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(cus), dim3(512), lds, s, g, tiles_m, tiles_n);
+        MILAN_CHECK_HIP(hipGetLastError());
+        return 0;
+      }
+    }
     return launch_split16_impl<BM, BN, STAGES, 3>(g, s);
+  }
   return launch_split16_impl<BM, BN, STAGES, 0>(g, s);
 }
 

@@ -1,5 +1,5 @@
 // micro-benchmark harness over libmilan_hip's internal launch_gemm (scratch)
-#include "../neuron-descriptions_amd/csrc/common.h"
+#include "../../neuron-descriptions_amd/csrc/common.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -37,6 +37,15 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+    {  // experiments build: per-phase cycles (wave 0 of every workgroup, averaged per tile)
+      long long* pr; CK(hipMalloc((void**)&pr, 128)); CK(hipMemset(pr, 0, 128));
+      g.prof = pr; launch_gemm(g, 0); CK(hipDeviceSynchronize()); g.prof = nullptr;
+      long long hp[16]; CK(hipMemcpy(hp, pr, 128, hipMemcpyDeviceToHost));
+      const double tiles = (double)((c.M + 255) / 256) * ((c.N + 255) / 256);
+      if (hp[2]) printf("  cycles per tile: prologue issue %.0f, fill wait %.0f, main loop %.0f, drain + scale %.0f, epilogue %.0f\n",
+                        hp[0] / tiles, hp[1] / tiles, hp[2] / tiles, hp[3] / tiles, hp[4] / tiles);
+      hipFree(pr);
+    }
     const double bytes = 4.0 * ((double)c.M * c.K + (double)c.M * c.N * (c.res ? 2 : 1));
     const double fl = 2.0 * c.M * c.N * c.K;
     printf("M=%ld N=%d K=%d res=%d hint=%d: %.3f ms  %.1f TF-eq  %.2f TB/s alg  (%.1f us per tile-round of 256 WG)\n",
