@@ -603,3 +603,32 @@ def test_split_f16_decoder_matches_reference_goldens(dev, goldens, golden_meta):
     outb = ctx.decode(feats, hip.RERANK, 15, 16, False, 0.2)
     _check_beams(outb, want_t, want_s, want_t.shape[2])
     ctx.close()
+
+
+@pytest.mark.parametrize('n,hw,cin,cout,res', [
+    (8, 96, 256, 512, False),    # 288 x 2 tiles of 256 x 256 on 256 CUs: persistent workgroups
+    (8, 95, 256, 1024, True),    # ragged last row tile, residual epilogue (an expand conv)
+    (40, 28, 1024, 256, False),  # K = 1024, one column of tiles (a reduce conv)
+])
+def test_persistent_1x1_kernel_equals_the_one_tile_per_workgroup_kernel(dev, n, hw, cin,
+                                                                         cout, res):
+    """1x1 convolutions with more 256 x 256 tiles than CUs run as persistent workgroups
+    that prefetch the next tile's A rows (igemm_split16_linp_kernel); the same rows
+    computed image by image stay below that threshold and take the plain kernel.  Same
+    k order, same epilogue: the results must agree bit for bit -- and with fp64."""
+    g = torch.Generator().manual_seed(n * hw + cin)
+    x = torch.randn(n, hw, hw, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    r = torch.randn(n, hw, hw, cout, generator=g).to(dev) if res else None
+    whole = hip.conv2d_nhwc(x, wt, b, 1, 0, relu=True, residual=r, precision='split_f16')
+    parts = torch.cat([
+        hip.conv2d_nhwc(x[i:i + 1], wt, b, 1, 0, relu=True,
+                        residual=None if r is None else r[i:i + 1], precision='split_f16')
+        for i in range(n)])
+    assert torch.equal(whole, parts)
+    want = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), b.double())
+    if r is not None:
+        want = want + r.permute(0, 3, 1, 2).double()
+    want = want.relu().permute(0, 2, 3, 1)
+    assert (whole.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
