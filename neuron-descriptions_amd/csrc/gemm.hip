@@ -869,7 +869,8 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
 
 #if MILAN_EXPERIMENTS
   long long pt_last = g.prof ? clock64() : 0;
-#define G_STAMP(k) do { if (g.prof) { const long long t1 = clock64(); if (tid == 0) atomicAdd((unsigned long long*)g.prof + (k), (unsigned long long)(t1 - pt_last)); pt_last = t1; } } while (0)
+  long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define G_STAMP(k) do { if (g.prof) { const long long t1 = clock64(); pt_acc[k] += t1 - pt_last; pt_last = t1; } } while (0)
 #else
 #define G_STAMP(k) do {} while (0)
 #endif
@@ -892,9 +893,12 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
 #pragma unroll
       for (int q = 0; q < LOADS; ++q) issue_piece(nxt, q);
     }
+    G_STAMP(5);  // (experiments, with GemmArgs::prof: compute / DMA wait / barrier inside the loop)
     // tile kt+1 must have landed; the AHEAD-1 younger tiles stay in flight
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
+    G_STAMP(6);
     if (!abl_bar) __builtin_amdgcn_s_barrier();
+    G_STAMP(7);
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
   G_STAMP(2);
@@ -920,6 +924,11 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   run_epilogue<TM, TN>(g, acc, smem, wave, lane, tile_m * BM + wm * WROWS,
                        tile_n * BN + wn * 64);
   G_STAMP(4);
+#if MILAN_EXPERIMENTS
+  if (g.prof && tid == 0)
+    for (int k = 0; k < 8; ++k)
+      atomicAdd((unsigned long long*)g.prof + k, (unsigned long long)pt_acc[k]);
+#endif
 }
 
 template <int BM, int BN, int STAGES, int SHAPE>

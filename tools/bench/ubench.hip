@@ -42,8 +42,9 @@ int main(int argc, char** argv) {
       g.prof = pr; launch_gemm(g, 0); CK(hipDeviceSynchronize()); g.prof = nullptr;
       long long hp[16]; CK(hipMemcpy(hp, pr, 128, hipMemcpyDeviceToHost));
       const double tiles = (double)((c.M + 255) / 256) * ((c.N + 255) / 256);
-      if (hp[2]) printf("  cycles per tile: prologue issue %.0f, fill wait %.0f, main loop %.0f, drain + scale %.0f, epilogue %.0f\n",
-                        hp[0] / tiles, hp[1] / tiles, hp[2] / tiles, hp[3] / tiles, hp[4] / tiles);
+      const double kts = tiles * (c.K / 16);
+      if (hp[5]) printf("  cycles per tile (wave 0): prologue issue %.0f, fill wait %.0f, drain + scale %.0f, epilogue %.0f; per k-tile: compute + DMA issue %.0f, DMA wait %.0f, barrier %.0f\n",
+                        hp[0] / tiles, hp[1] / tiles, hp[3] / tiles, hp[4] / tiles, hp[5] / kts, hp[6] / kts, (hp[7] + hp[2]) / kts);
       hipFree(pr);
     }
     const double bytes = 4.0 * ((double)c.M * c.K + (double)c.M * c.N * (c.res ? 2 : 1));
