@@ -817,7 +817,12 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   // issued between the MFMA groups and the A fragments of row-tile i+1 are
   // fetched while row-tile i multiplies, so address arithmetic, DMA issue and
   // LDS latency hide under the matrix pipe.
-  auto compute = [&](int cur, int nxt) {
+  // DMA_POS: 0 the DMA pieces between the MFMA row groups; 1 all of them ahead of the
+  // MFMAs, 2 all behind.  In the 8-wave tile the two waves of a SIMD run 1 and 2 (see
+  // igemm_split16_linp_kernel: an LDS-DMA instruction holds its wave for 150-200 cycles;
+  // with the same order in both waves the stalls coincide and the matrix pipe idles).
+  auto compute = [&](int cur, int nxt, auto pos_tag) {
+    constexpr int DMA_POS = decltype(pos_tag)::value;
     const float* Ab = As + cur * (BM * BK);
     const float* Bb = Bs + cur * (BN * BK);
     // lanes 0-31: group 0 (channels 0-7), lanes 32-63: group 1 (channels 8-15)
@@ -831,6 +836,11 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
     ah[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((chi ^ aswz[0]) << 2));
     al[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((clo ^ aswz[0]) << 2));
     constexpr int PER = (LOADS + TM - 1) / TM;  // pieces per MFMA group
+    if constexpr (DMA_POS == 1) {
+#pragma unroll
+      for (int q = 0; q < LOADS; ++q) issue_piece(nxt, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if (i + 1 < TM) {
@@ -839,9 +849,11 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
         al[i + 1] = *reinterpret_cast<const f32x4*>(Ab + aoff[i + 1] +
                                                     ((clo ^ aswz[i + 1]) << 2));
       }
+      if constexpr (DMA_POS == 0) {
 #pragma unroll
-      for (int q = 0; q < PER; ++q)
-        if (i * PER + q < LOADS) issue_piece(nxt, i * PER + q);
+        for (int q = 0; q < PER; ++q)
+          if (i * PER + q < LOADS) issue_piece(nxt, i * PER + q);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -851,6 +863,11 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
             as_f16x8(ah[i]), as_f16x8(bh[j]), acc[i][j], 0, 0, 0);
       }
+    }
+    if constexpr (DMA_POS == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < LOADS; ++q) issue_piece(nxt, q);
     }
     if constexpr (MILAN_EXPERIMENTS && SHAPE == 1) {
       // issue-slot shaping: fragments of the first row-tile, then one MFMA
@@ -885,22 +902,28 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
   G_STAMP(1);
   int cur = 0;
   const int nk_run = (MILAN_ABLATE_BUILD && (g.debug & 4)) ? 0 : nk;  // epilogue only
-  for (int kt = 0; kt < nk_run; ++kt) {
-    int nxt = cur + AHEAD;
-    nxt = nxt >= STAGES ? nxt - STAGES : nxt;
-    if (!abl_mfma) compute(cur, nxt);
-    else {
+  auto k_loop = [&](auto pos_tag) {
+    for (int kt = 0; kt < nk_run; ++kt) {
+      int nxt = cur + AHEAD;
+      nxt = nxt >= STAGES ? nxt - STAGES : nxt;
+      if (!abl_mfma) compute(cur, nxt, pos_tag);
+      else {
 #pragma unroll
-      for (int q = 0; q < LOADS; ++q) issue_piece(nxt, q);
+        for (int q = 0; q < LOADS; ++q) issue_piece(nxt, q);
+      }
+      G_STAMP(5);  // (experiments, with GemmArgs::prof: compute / DMA wait / barrier inside the loop)
+      // tile kt+1 must have landed; the AHEAD-1 younger tiles stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
+      G_STAMP(6);
+      if (!abl_bar) __builtin_amdgcn_s_barrier();
+      G_STAMP(7);
+      cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
-    G_STAMP(5);  // (experiments, with GemmArgs::prof: compute / DMA wait / barrier inside the loop)
-    // tile kt+1 must have landed; the AHEAD-1 younger tiles stay in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
-    G_STAMP(6);
-    if (!abl_bar) __builtin_amdgcn_s_barrier();
-    G_STAMP(7);
-    cur = cur + 1 == STAGES ? 0 : cur + 1;
-  }
+  };
+  // (the two waves of a SIMD issuing their pieces at opposite ends of the iteration -- what
+  // igemm_split16_linp_kernel does -- measured SLOWER here: layer3 119.8 -> 123.9 ms per 256
+  // neurons; this kernel's pieces carry the tap arithmetic and stay between the MFMA groups)
+  k_loop(std::integral_constant<int, 0>{});
   G_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tiles
   __builtin_amdgcn_s_barrier();
@@ -925,9 +948,9 @@ __device__ __forceinline__ void split16_tile(const GemmArgs& g, int tile_m,
                        tile_n * BN + wn * 64);
   G_STAMP(4);
 #if MILAN_EXPERIMENTS
-  if (g.prof && tid == 0)
+  if (g.prof && lane == 0)  // 8 counters per wave: waves 1.. at prof[8 * wave + k]
     for (int k = 0; k < 8; ++k)
-      atomicAdd((unsigned long long*)g.prof + k, (unsigned long long)pt_acc[k]);
+      atomicAdd((unsigned long long*)g.prof + 8 * wave + k, (unsigned long long)pt_acc[k]);
 #endif
 }
 
@@ -968,7 +991,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
   constexpr int BM = 256, BN = 256, BK = 16, TM = 4, TN = 2;
   constexpr int WROWS = TM * 32, WAVES_N = BN / 64, LROWS = 128;
   constexpr int A_ITERS = BM / LROWS, B_ITERS = BN / LROWS, LOADS = A_ITERS + B_ITERS;
-  constexpr int AHEAD = STAGES - 1;
+  constexpr int AHEAD = STAGES - 1, NT_WAVES = 8;
   static_assert(STAGES == 5 && LOADS == TM, "one DMA piece per MFMA row group");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                        // [STAGES][BM*16]
@@ -1083,8 +1106,14 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
     // MFMAs of the k-tile in ring slot `cur`; one DMA piece between the MFMA groups:
     // STEADY the A and W rows of this tile's k-tile `kt_issue`; otherwise (tail) the A
     // rows of the next tile's k-tile `kt_issue`, if there is a next tile
-    auto compute = [&](int cur_slot, int nxt_slot, int kt_issue, auto steady_tag) {
+    // DMA_POS (steady state): 0 one piece between the MFMA row groups, 1 all four pieces
+    // ahead of the MFMAs, 2 all four behind them.  The two waves of a SIMD run 1 and 2:
+    // an LDS-DMA instruction holds its wave for 150-200 cycles, and with the same
+    // instruction order in both waves those stalls coincide and the matrix pipe idles
+    // (in-kernel profile: the second wave of each SIMD finished 540 cycles late).
+    auto compute = [&](int cur_slot, int nxt_slot, int kt_issue, auto steady_tag, auto pos_tag) {
       constexpr bool STEADY = decltype(steady_tag)::value;
+      constexpr int DMA_POS = decltype(pos_tag)::value;
       const float* Ab = As + cur_slot * (BM * BK);
       const float* Bb = Bs + cur_slot * (BN * BK);
       const int chi = 2 * fhalf, clo = chi + 1;
@@ -1096,6 +1125,13 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
       }
       ah[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((chi ^ aswz[0]) << 2));
       al[0] = *reinterpret_cast<const f32x4*>(Ab + aoff[0] + ((clo ^ aswz[0]) << 2));
+      if constexpr (STEADY && DMA_POS == 1) {
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) issue_a(ra, it, kt_issue, nxt_slot);
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) issue_b(it, kt_issue, nxt_slot);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (i + 1 < TM) {
@@ -1105,8 +1141,10 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
                                                       ((clo ^ aswz[i + 1]) << 2));
         }
         if constexpr (STEADY) {
-          if (i < A_ITERS) issue_a(ra, i, kt_issue, nxt_slot);
-          else issue_b(i - A_ITERS, kt_issue, nxt_slot);
+          if constexpr (DMA_POS == 0) {
+            if (i < A_ITERS) issue_a(ra, i, kt_issue, nxt_slot);
+            else issue_b(i - A_ITERS, kt_issue, nxt_slot);
+          }
         } else {
           if (i < A_ITERS && has_next) issue_a(ra_n, i, kt_issue, nxt_slot);
         }
@@ -1120,23 +1158,34 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
               as_f16x8(ah[i]), as_f16x8(bh[j]), acc[i][j], 0, 0, 0);
         }
       }
+      if constexpr (STEADY && DMA_POS == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) issue_a(ra, it, kt_issue, nxt_slot);
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) issue_b(it, kt_issue, nxt_slot);
+      }
     };
     auto advance = [&]() { cur = cur + 1 == STAGES ? 0 : cur + 1; };
     auto slot_ahead = [&]() { const int n = cur + AHEAD; return n >= STAGES ? n - STAGES : n; };
 
     // steady state: k-tile kt + AHEAD of this tile is issued under k-tile kt
-    for (int kt = 0; kt + AHEAD < nk; ++kt) {
-      compute(cur, slot_ahead(), kt + AHEAD, std::true_type{});
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
-      __builtin_amdgcn_s_barrier();
-      advance();
-    }
+    auto steady_loop = [&](auto pos_tag) {
+      for (int kt = 0; kt + AHEAD < nk; ++kt) {
+        compute(cur, slot_ahead(), kt + AHEAD, std::true_type{}, pos_tag);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * LOADS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        advance();
+      }
+    };
+    if (wave < NT_WAVES / 2) steady_loop(std::integral_constant<int, 1>{});
+    else steady_loop(std::integral_constant<int, 2>{});
     // tail: the last AHEAD k-tiles.  Before k-tile (current + 1) starts it must have
     // landed; what was issued after it -- the rest of this tile, the next tile's A rows
     // -- may still fly (the last tile of a workgroup issues nothing and drains)
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t) {
-      compute(cur, slot_ahead(), t, std::false_type{});
+      compute(cur, slot_ahead(), t, std::false_type{}, std::integral_constant<int, 0>{});
       if (t + 1 < AHEAD) {
         if (has_next) {
           if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS + A_ITERS) : "memory");

@@ -38,13 +38,16 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
     {  // experiments build: per-phase cycles (wave 0 of every workgroup, averaged per tile)
-      long long* pr; CK(hipMalloc((void**)&pr, 128)); CK(hipMemset(pr, 0, 128));
+      long long* pr; CK(hipMalloc((void**)&pr, 1024)); CK(hipMemset(pr, 0, 1024));
       g.prof = pr; launch_gemm(g, 0); CK(hipDeviceSynchronize()); g.prof = nullptr;
-      long long hp[16]; CK(hipMemcpy(hp, pr, 128, hipMemcpyDeviceToHost));
+      long long hp[128]; CK(hipMemcpy(hp, pr, 1024, hipMemcpyDeviceToHost));
       const double tiles = (double)((c.M + 255) / 256) * ((c.N + 255) / 256);
       const double kts = tiles * (c.K / 16);
       if (hp[5]) printf("  cycles per tile (wave 0): prologue issue %.0f, fill wait %.0f, drain + scale %.0f, epilogue %.0f; per k-tile: compute + DMA issue %.0f, DMA wait %.0f, barrier %.0f\n",
                         hp[0] / tiles, hp[1] / tiles, hp[3] / tiles, hp[4] / tiles, hp[5] / kts, hp[6] / kts, (hp[7] + hp[2]) / kts);
+      if (hp[5]) for (int wv = 0; wv < 8; ++wv)
+        printf("    wave %d per k-tile: compute + issue %.0f, DMA wait %.0f, barrier %.0f; epilogue %.0f\n", wv, hp[8 * wv + 5] / kts,
+               hp[8 * wv + 6] / kts, (hp[8 * wv + 7] + hp[8 * wv + 2]) / kts, hp[8 * wv + 4] / tiles);
       hipFree(pr);
     }
     const double bytes = 4.0 * ((double)c.M * c.K + (double)c.M * c.N * (c.res ? 2 : 1));
