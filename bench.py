@@ -26,8 +26,10 @@ WHOLE-JOB size instead (rank r takes `partition(T, N, r, align=16)`; "scaling":
 "strong"): `--gpus 8 --neurons-total 4096` is BASELINE's metric as quoted.
 
     python bench.py                      # 1 GPU
+    python bench.py --gpus 8             # launches its own 8 ranks (torch.distributed.run)
+    python bench.py --gpus 8 --neurons-total 4096   # the SCALE line: BASELINE's metric as quoted
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
-        --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8
+        --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8   # the driver's form
 """
 import argparse
 import hashlib
@@ -405,11 +407,27 @@ def main():
                     'runs only)')
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without torchrun: this process becomes the
+    # launcher of N ranks (torch.distributed.run on 127.0.0.1, a free port);
+    # rank 0 of that job prints the JSON line.  Under torchrun (the driver's
+    # launch line) RANK / WORLD_SIZE are set and this is one of the ranks.
+    if args.gpus > 1 and not sharding.launched_by_torchrun():
+        sys.exit(sharding.self_launch(str(pathlib.Path(__file__).resolve()),
+                                      sys.argv[1:], args.gpus))
+
     rank, world, local = sharding.init_from_env(args.gpus)
-    # one GPU per rank; `% device_count` only matters for the debug set-up of
-    # several gloo ranks sharing the single GPU of a test box
-    device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
+    # one GPU per rank; `% device_count` only matters when several ranks share the
+    # single GPU of a test box (collectives over gloo then, sharding.self_launch)
+    n_dev = max(1, torch.cuda.device_count())
+    device = torch.device('cuda', local % n_dev)
     torch.cuda.set_device(device)
+    shared = -(-world // n_dev)  # ranks per GPU
+    if shared > 1:
+        # every rank holds its own activation workspace (0.24 GB per neuron of the
+        # chunk) and exemplar pool: size the chunk to this rank's share of the HBM
+        total = torch.cuda.get_device_properties(device).total_memory
+        fit = int(0.6 * total / shared / 0.25e9) // 64 * 64
+        args.chunk = max(64, min(args.chunk, fit))
 
     # roofline.traffic, measured live: two child passes of ONE step under rocprofv3
     # --pmc, run FIRST -- before this process holds its 150 GB of workspace

@@ -41,6 +41,43 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def launched_by_torchrun() -> bool:
+    """True inside a process that `torch.distributed.run` (or any launcher that
+    exports the same variables) started as one rank of a job."""
+    return 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+
+
+def self_launch(script: str, argv: Sequence[str], nproc: int) -> int:
+    """Re-run `script argv...` as `nproc` ranks of one node and return the job's
+    exit code (the caller is the launcher from then on and must not compute).
+
+    `python bench.py --gpus 8` started WITHOUT torchrun ends up here: the ranks
+    are started with `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1` on a free port, one rank per GPU
+    over RCCL.  On a box with fewer GPUs than ranks (a 1-GPU test box) the ranks
+    share the GPUs (`local_rank % device_count`) and the two collectives are
+    staged through host memory (gloo): RCCL cannot put two ranks on one device.
+    """
+    import socket
+    import subprocess
+    import sys
+    if nproc < 2:
+        raise ValueError(f'self_launch needs nproc >= 2, got {nproc}')
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    devices = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if devices < nproc:
+        env.setdefault('MILAN_DIST_BACKEND', 'gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), script, *argv]
+    return subprocess.call(cmd, env=env)
+
+
 def init_from_env(expected_world: Optional[int] = None,
                   backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).

@@ -4,9 +4,10 @@ Command-line contract of the reference's `scripts/compute_milan_descriptions.py`
 (positional `model dataset`, `--temperature --beam-size --data-dir
 --results-dir --milan --device`, CSV `layer,unit,description` named
 `<model>_<dataset>.csv`), so existing job scripts keep working.  Additions:
-`--milan-path` (there is no downloader here) and multi-GPU sharding -- under
-`torchrun --nproc-per-node N` every rank describes a contiguous block of the
-neurons and rank 0 writes the CSV in the reference's order.
+`--milan-path` (there is no downloader here) and multi-GPU sharding -- with
+`--gpus N` (the script starts its own N ranks) or under `torchrun
+--nproc-per-node N` every rank describes a contiguous block of the neurons and
+rank 0 writes the CSV in the reference's order.
 """
 import argparse
 import csv
@@ -41,6 +42,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument('--results-dir', type=pathlib.Path,
                    help='root dir for final results')
     p.add_argument('--device', help='manually set device (default: cuda)')
+    p.add_argument('--gpus', type=int, default=1,
+                   help='GPUs of this node to shard the neurons over: N > 1 '
+                   'without torchrun starts N ranks itself (default: 1)')
     return p.parse_args(argv)
 
 
@@ -79,8 +83,13 @@ def csv_rows(dataset, captions: Sequence[str]) -> List[Tuple[str, str, str]]:
 
 def main(argv=None) -> None:
     args = parse_args(argv)
+    if args.gpus > 1 and not sharding.launched_by_torchrun():
+        # become the launcher of `--gpus` ranks (one per GPU, RCCL)
+        sys.exit(sharding.self_launch(
+            str(pathlib.Path(__file__).resolve()),
+            sys.argv[1:] if argv is None else list(argv), args.gpus))
     rank, world, local = sharding.init_from_env()
-    device = args.device or f'cuda:{local}'
+    device = args.device or f'cuda:{local % max(1, torch.cuda.device_count())}'
     key = f'{args.model}/{args.dataset}'
 
     # rank 0 reads the checkpoint; the others get it by RCCL broadcast
