@@ -1219,6 +1219,305 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Round 4: the 256 x 256 split16 tile as a TWO-GROUP PING-PONG (igemm_split16_pp_kernel).
+//
+// The lockstep loop above keeps the matrix pipe ~65 % busy in cycles: all eight waves come
+// out of the k-tile barrier together, all read their fragments, and the two waves of a SIMD
+// stall on the same things at the same time.  Here the workgroup is two groups of four
+// waves (one wave of each group per SIMD; group = row half of the tile) that alternate
+// roles every phase:
+//
+//   phase 2t     group 0 multiplies k-tile t (24 MFMAs, nothing else in its stream)
+//                group 1 reads its 12 fragments of k-tile t from LDS, issues the 4 DMA
+//                pieces of k-tile t + 3 and waits for its own pieces of k-tile t + 1
+//   phase 2t + 1 group 0 reads k-tile t + 1 / issues k-tile t + 4, group 1 multiplies t
+//
+// with one s_barrier per phase.  What makes the read phase fit under the partner's 768
+// MFMA cycles is that it holds NO vector-ALU instruction (two waves of a SIMD share its
+// VALU port, and beside an MFMA stream every VALU op of the partner costs ~10-20 cycles):
+//   * operands go L2 -> LDS by buffer_load ... lds: descriptor (SGPRs) + a loop-invariant
+//     per-lane 32-bit row offset + a SCALAR k offset; rows past M / N and out-of-image
+//     taps carry an out-of-range offset, for which the hardware writes zeros into LDS (no
+//     zero page, no per-lane select per piece);
+//   * the ring has 4 slots and the k loop is unrolled 4 x, so every ds_read_b128 is one
+//     base register + an immediate;
+//   * the per-lane tap bounds test runs once per (kh, kw), not per k-tile.
+// Prototype and measurements: tools/bench/pp.hip, profiles/r4_mainloop_prototype.txt
+// (1570-1650 cycles per k-tile against 2210-2280 for the lockstep loop; ideal 1536).
+// Same k order and the same (hl, lh, hh) order per accumulator as the kernels above:
+// bitwise the same results.
+// ---------------------------------------------------------------------------
+// GemmArgs re-read from the kernel-argument segment (it is the first kernel argument:
+// offset 0) through a pointer the compiler cannot see through.  Values loaded this way
+// are not hoisted above the point of the call: split16_pp_tile uses it so that neither
+// the next tile's set-up inputs nor the epilogue's arguments occupy scalar registers
+// during the main loop (they spilled into vector registers and from there to scratch --
+// VALU and VMEM traffic inside a loop whose waits count VMEM operations).
+__device__ __forceinline__ GemmArgs reload_gemm_args() {
+  typedef const int __attribute__((address_space(4)))* KArgWords;
+  KArgWords kw = (KArgWords)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kw));
+  GemmArgs g;
+  int words[sizeof(GemmArgs) / 4];
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) words[i] = kw[i];
+  __builtin_memcpy(&g, words, sizeof(GemmArgs));
+  return g;
+}
+
+__device__ __forceinline__ void split16_pp_tile(int tile_m, int tile_n, int tid) {
+  const GemmArgs g = reload_gemm_args();
+  constexpr int BM = 256, BN = 256, BK = 16, S = 4, TM = 4, TN = 2, LOADS = 4;
+  constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor below
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [S][BM * 16]
+  float* Bs = smem + S * BM * BK;   // [S][BN * 16]
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- loader state --------------------------------------------------------------
+  const int lrow = tid >> 2;                        // 0..127
+  const int kc = (tid & 3) ^ ((tid >> 4) & 3);      // source chunk of this lane's LDS slot
+  const int HoWo = g.Ho * g.Wo;
+  const int img0 = (tile_m * BM) / HoWo;            // first image of the tile (scalar)
+  // descriptors: A from (image img0, pixel (-pad, -pad)) so that every per-lane offset is
+  // non-negative; W from the tile's first row
+  const long bias = ((long)g.pad * g.Wd + g.pad) * g.a_pix_stride;
+  const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A + (long)img0 * g.a_img_stride - bias), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_a2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A2 ? g.A2 + (long)img0 * g.a2_img_stride : g.A), 0, 0x7fffffff,
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.W + (long)tile_n * BN * g.Kp), 0, 0x7fffffff, 0x00020000);
+  unsigned row_off[2], row_off2[2], voff[2], vb[2];
+  int hi0[2], wi0[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int m = tile_m * BM + it * 128 + lrow;
+    const bool ok = m < g.M;
+    const int mm = ok ? m : g.M - 1;
+    const int img = mm / HoWo;
+    const int rem = mm - img * HoWo;
+    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+    hi0[it] = ho * g.stride - g.pad;
+    wi0[it] = wo * g.stride - g.pad;
+    row_off[it] = ok ? (unsigned)(((long)(img - img0) * g.a_img_stride +
+                                   ((long)hi0[it] * g.Wd + wi0[it]) * g.a_pix_stride + bias +
+                                   kc * 4) * 4)
+                     : OOB;
+    row_off2[it] = (ok && g.A2)
+                       ? (unsigned)(((long)(img - img0) * g.a2_img_stride +
+                                     ((long)(ho * g.stride2) * g.W2d + wo * g.stride2) *
+                                         g.a2_pix_stride + kc * 4) * 4)
+                       : OOB;
+    const int n = tile_n * BN + it * 128 + lrow;
+    vb[it] = n < g.N ? (unsigned)(((long)(it * 128 + lrow) * g.Kp + kc * 4) * 4) : OOB;
+  }
+  const int nk = g.Kp / BK;
+  const int k1_tiles = g.A2 ? g.K1 / BK : 0x7fffffff;
+  // The k-tile the loader issues next: index, tap, first channel.  ONE code path per piece:
+  // the A source of the moment is (descriptor cur_srd, per-lane offsets voff[], scalar
+  // offset seg_soff + 4 * is_cin0); a tap change or the switch to the second source (once
+  // per tile) rewrites that state.
+  int is_kt = 0, is_kh = 0, is_kw = 0, is_cin0 = 0, seg_soff = 0;
+  int cin_limit = g.Cin;
+  __amdgpu_buffer_rsrc_t cur_srd = srd_a;
+  auto set_tap = [&]() {  // per-lane bounds of tap (is_kh, is_kw): once per tap, not per k-tile
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const bool inb = (unsigned)(hi0[it] + is_kh) < (unsigned)g.H &&
+                       (unsigned)(wi0[it] + is_kw) < (unsigned)g.Wd;
+      voff[it] = inb ? row_off[it] : OOB;
+    }
+    seg_soff = (int)((((long)is_kh * g.Wd + is_kw) * g.a_pix_stride) * 4);
+  };
+  set_tap();
+  auto issue_tile = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    // (opaque: sixteen loop-invariant LDS addresses are not worth sixteen scalar registers)
+    int woff = wave * (16 * BK);
+    asm volatile("" : "+s"(woff));
+    float* adst = As + SLOT * (BM * BK) + woff;
+    float* bdst = Bs + SLOT * (BN * BK) + woff;
+    const int soff = seg_soff + is_cin0 * 4;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_srd, (LDS_AS void*)adst, 16, voff[0], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_srd, (LDS_AS void*)(adst + 128 * BK), 16, voff[1],
+                                             soff, 0, 0);
+    const int woffk = is_kt * (BK * 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (LDS_AS void*)bdst, 16, vb[0], woffk, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (LDS_AS void*)(bdst + 128 * BK), 16, vb[1],
+                                             woffk, 0, 0);
+    // advance; past the end of K the last k-tile is fetched again into slots nobody reads
+    // (every phase issues exactly LOADS pieces: constant vmcnt counts)
+    if (is_kt + 1 < nk) {
+      ++is_kt;
+      is_cin0 += BK;
+      if (is_kt == k1_tiles) {
+        // second source from here on: a 1x1 / stride2 input, always in bounds, k from K1
+        cur_srd = srd_a2;
+        voff[0] = row_off2[0];
+        voff[1] = row_off2[1];
+        seg_soff = 0;
+        is_cin0 = 0;
+        cin_limit = 0x7fffffff;
+      } else if (is_cin0 >= cin_limit) {
+        is_cin0 = 0;
+        if (++is_kw == g.KW) { is_kw = 0; ++is_kh; }
+        set_tap();
+      }
+    }
+  };
+
+  // ---- fragments -------------------------------------------------------------------
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int swz = (frow >> 2) & 3;
+  const int chi = (2 * fhalf) ^ swz, clo = (2 * fhalf + 1) ^ swz;
+  const float* a_hi = As + (wm * 128 + frow) * BK + (chi << 2);
+  const float* a_lo = As + (wm * 128 + frow) * BK + (clo << 2);
+  const float* b_hi = Bs + (wn * 64 + frow) * BK + (chi << 2);
+  const float* b_lo = Bs + (wn * 64 + frow) * BK + (clo << 2);
+  f32x4 ah[TM], al[TM], bh[TN], bl[TN];
+  auto read_frags = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[j] = *reinterpret_cast<const f32x4*>(b_hi + SLOT * (BN * BK) + j * 32 * BK);
+      bl[j] = *reinterpret_cast<const f32x4*>(b_lo + SLOT * (BN * BK) + j * 32 * BK);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ah[i] = *reinterpret_cast<const f32x4*>(a_hi + SLOT * (BM * BK) + i * 32 * BK);
+      al[i] = *reinterpret_cast<const f32x4*>(a_lo + SLOT * (BM * BK) + i * 32 * BK);
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // the 24 MFMAs of a k-tile, product-major (every accumulator once per product; per
+  // accumulator the order is hl, lh, hh as in the kernels above)
+  auto multiply = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(ah[i]), as_f16x8(bl[j]),
+                                                           acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(al[i]), as_f16x8(bh[j]),
+                                                           acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(ah[i]), as_f16x8(bh[j]),
+                                                           acc[i][j], 0, 0, 0);
+  };
+  // a phase boundary: nothing is scheduled across it (an MFMA is register-only, the
+  // "memory" clobber of the waits would not hold it)
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // read phase of the k-tile in ring slot SLOT: fragments, then the pieces of the k-tile
+  // three ahead into the slot both groups are done with
+  auto read_phase = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    read_frags(slot_tag);
+    issue_tile(std::integral_constant<int, (SLOT + S - 1) % S>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // prologue: k-tiles 0 .. S-2 in flight, k-tile 0 landed
+  issue_tile(std::integral_constant<int, 0>{});
+  issue_tile(std::integral_constant<int, 1>{});
+  issue_tile(std::integral_constant<int, 2>{});
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LOADS) : "memory");
+  phase_barrier();
+  if (wm == 0) {
+    read_phase(std::integral_constant<int, 0>{});
+    phase_barrier();
+    auto step = [&](auto slot_tag) {  // k-tile kt in slot SLOT: multiply it, then read kt + 1
+      constexpr int SLOT = decltype(slot_tag)::value;
+      multiply();
+      __builtin_amdgcn_sched_barrier(0);
+      // every wave has its own pieces of k-tile kt + 1 before the barrier that precedes
+      // the first read of it; two younger k-tiles stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LOADS) : "memory");
+      phase_barrier();
+      read_phase(std::integral_constant<int, (SLOT + 1) % S>{});
+      phase_barrier();
+    };
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 4) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+    }
+    if (kt < nk) {  // Kp is a multiple of 32: nk is even
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+    }
+  } else {
+    phase_barrier();
+    auto step = [&](auto slot_tag) {  // k-tile kt in slot SLOT: read it, then multiply it
+      read_phase(slot_tag);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LOADS) : "memory");
+      phase_barrier();
+      multiply();
+      phase_barrier();
+    };
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 4) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+    }
+    if (kt < nk) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+    }
+  }
+  // the re-fetched tail k-tiles have landed and every wave is done with the ring before it
+  // becomes the epilogue's staging
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const GemmArgs ge = reload_gemm_args();  // the epilogue's arguments, loaded here
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * ge.acc_scale;
+  run_epilogue<TM, TN>(ge, acc, smem, wave, lane, tile_m * BM + wm * 128, tile_n * BN + wn * 64);
+}
+
+__global__ __launch_bounds__(512, 2) void igemm_split16_pp_kernel(GemmArgs g, int tiles_m,
+                                                                  int tiles_n) {
+  // one tile per workgroup (gridDim.x == tiles), or workgroups walking tiles q = blockIdx.x,
+  // + gridDim.x, ... (gridDim.x a multiple of 8: q stays on its XCD)
+  const int T = tiles_m * tiles_n;
+  for (int q = blockIdx.x; q < T; q += gridDim.x) {
+    const int tile = xcd_tile(q, T);
+    const int tile_m = tile / tiles_n;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    split16_pp_tile(tile_m, tile - tile_m * tiles_n, tid);
+    // the epilogue's staging reads are done before the next tile's DMA lands there
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
 // The same pipeline with 64 x 64 wave tiles (4 waves per 256 x 64 block, two
 // blocks per CU): the N = 64 layers of layer1.
 template <int BM, int BN, int STAGES>
@@ -1728,8 +2027,46 @@ static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
   return 0;
 }
 
+// the ping-pong form of the 256 x 256 tile (4-slot ring: 128 KB of LDS)
+static int launch_split16_pp(const GemmArgs& g, hipStream_t s) {
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+  const size_t lds = size_t(4) * (256 + 256) * 16 * sizeof(float);
+  static_assert(size_t(4) * 512 * 16 * sizeof(float) >= size_t(8) * 32 * 68 * sizeof(float),
+                "the epilogue stages through the ring");
+  auto kern = igemm_split16_pp_kernel;
+  int dev = 0;
+  MILAN_CHECK_HIP(hipGetDevice(&dev));
+  static std::vector<char> attr_set(64, 0);  // per device
+  if (dev < 64 && !attr_set[dev]) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dev] = 1;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, g, tiles_m, tiles_n);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// per-launch limits of the ping-pong kernel's 32-bit buffer offsets: a tile's rows span
+// less than 2 GB of the input, the weight panel of a tile less than 2 GB
+static bool pp_eligible(const GemmArgs& g) {
+  if (g.Cin % 16 != 0 || g.aniso) return false;
+  if (g.A2 && (g.K1 % 16 != 0)) return false;
+  const long howo = (long)g.Ho * g.Wo;
+  const long imgs = 256 / (howo > 0 ? howo : 1) + 2;  // images a 256-row tile can touch
+  const long a_span = imgs * g.a_img_stride * 4 + 64;
+  const long a2_span = g.A2 ? imgs * g.a2_img_stride * 4 + 64 : 0;
+  const long w_span = 256L * g.Kp * 4;
+  return a_span < 0x7fffffffL && a2_span < 0x7fffffffL && w_span < 0x7fffffffL;
+}
+
 template <int BM, int BN, int STAGES>
 static int launch_split16(const GemmArgs& g, hipStream_t s) {
+  if constexpr (BM == 256 && BN == 256 && STAGES == 5) {
+    static int pp = -1;  // MILAN_PP=0: the round-3 lockstep kernels (same bits; A/B timing)
+    if (pp < 0) { const char* e = getenv("MILAN_PP"); pp = e ? atoi(e) : 1; }
+    if (pp && !g.chunk_major && pp_eligible(g)) return launch_split16_pp(g, s);
+  }
 #if MILAN_EXPERIMENTS
   static int shape = -1;
   if (shape < 0) { const char* e = getenv("MILAN_SCHED"); shape = e ? atoi(e) : 0; }
