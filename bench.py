@@ -427,7 +427,7 @@ def main():
         # chunk) and exemplar pool: size the chunk to this rank's share of the HBM
         total = torch.cuda.get_device_properties(device).total_memory
         fit = int(0.6 * total / shared / 0.25e9) // 64 * 64
-        args.chunk = max(64, min(args.chunk, fit))
+        args.chunk = min(args.chunk, max(64, fit))
 
     # roofline.traffic, measured live: two child passes of ONE step under rocprofv3
     # --pmc, run FIRST -- before this process holds its 150 GB of workspace

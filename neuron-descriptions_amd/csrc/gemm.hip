@@ -100,7 +100,7 @@ __device__ inline void join8(f32x4 hi, f32x4 lo, float* v) {
 // epilogue shared by all tile configurations (wave tile = TM x TN MFMA tiles,
 // rows row0.., columns col0..; TN == 2, i.e. 64 columns per wave)
 // ---------------------------------------------------------------------------
-template <int TM, int TN>
+template <int TM, int TN, bool SWZ64 = false>
 __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
                                              f32x16 (&acc)[TM][TN], float* smem,
                                              int wave, int lane, int row0,
@@ -108,7 +108,13 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
   static_assert(TN == 2, "epilogues assume 64-column wave tiles");
   // ---- epilogues ----------------------------------------------------------------
   // D layout (32x32): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  constexpr int SROW = 68;  // staging row stride (floats): 64 + 4 de-conflicts
+  // Staging rows: 64 floats + 4 of padding (the padding staggers consecutive rows over the
+  // banks), or -- SWZ64, 8 KB per wave: the persistent ping-pong kernel has exactly 64 KB of
+  // LDS to spare while its ring holds the next tile's prefetch -- 64 floats with the 16-byte
+  // chunk index XORed by the row's parity, which keeps the two rows of a split-format
+  // 16-lane read group on disjoint banks.
+  constexpr int SROW = SWZ64 ? 64 : 68;
+  auto sw = [](int row, int col) { return SWZ64 ? (col ^ ((row & 1) << 2)) : col; };
   float* stage_out = smem + wave * (32 * SROW);
   auto to_stage = [&](int i) {
 #pragma unroll
@@ -116,7 +122,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        stage_out[row * SROW + j * 32 + (lane & 31)] = acc[i][j][r];
+        stage_out[row * SROW + sw(row, j * 32 + (lane & 31))] = acc[i][j][r];
       }
     // same-wave LDS ops complete in order: no barrier needed
   };
@@ -154,7 +160,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
       for (int it = 0; it < 8; ++it) {
         const int row = it * 4 + (lane >> 4);
         const int m = row0 + i * 32 + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage_out + row * SROW + col4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage_out + row * SROW + sw(row, col4));
         if (m < g.M && n_ok) {
           v += bias4;
           if constexpr (AUX) {
@@ -229,9 +235,9 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
         const int row = it * 8 + (lane >> 3);
         const int m = row0 + i * 32 + row;
         const f32x4 v0 =
-            *reinterpret_cast<const f32x4*>(stage_out + row * SROW + col8);
+            *reinterpret_cast<const f32x4*>(stage_out + row * SROW + sw(row, col8));
         const f32x4 v1 =
-            *reinterpret_cast<const f32x4*>(stage_out + row * SROW + col8 + 4);
+            *reinterpret_cast<const f32x4*>(stage_out + row * SROW + sw(row, col8 + 4));
         if (m < g.M && n_ok) {
           float v[8];
 #pragma unroll
@@ -302,7 +308,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate)
           p[gate] = *reinterpret_cast<const f32x4*>(stage_out + row * SROW +
-                                                    gate * 16 + q4) + bias4[gate];
+                                                    sw(row, gate * 16 + q4)) + bias4[gate];
         if (m < g.M && n_ok) {
           f32x4 h4, c4;
 #pragma unroll
@@ -1502,6 +1508,372 @@ __device__ __forceinline__ void split16_pp_tile(int tile_m, int tile_n, int tid)
   run_epilogue<TM, TN>(ge, acc, smem, wave, lane, tile_m * BM + wm * 128, tile_n * BN + wn * 64);
 }
 
+// ---------------------------------------------------------------------------
+// The same ping-pong with the operands staged in k-tile PAIRS = whole 128-byte lines per
+// row (igemm_split16_pp32_kernel; needs Cin % 32 == 0).  A DMA piece of the kernel above
+// is 16 rows x 64 B: half a cache line per row, the other half asked for one k-tile later.
+// Measured (tools/bench/pp.hip E2): such pieces stream 4.0 TB/s from HBM and 66 B/clk/CU
+// from L2 where 8 rows x 128 B pieces reach 6.0 TB/s and 102 B/clk/CU -- and the 1x1 reduce
+// convs of layer3 (every workgroup streams its own 1 MB A panel) sat at 3.7 TB/s.
+//   * LDS rows of 128 B = two 16-slot slabs; the 16-byte chunk q = 4 * slab + 2 * group +
+//     (hi | lo) of row r lives at position q ^ ((r >> 1) & 7): conflict-free for the DMA
+//     write (lane-linear, the XOR is applied on the source address) and for the row-per-lane
+//     ds_read_b128 of either slab;
+//   * A ring of 3 pair slots (96 KB), W ring of 2 (64 KB): all 160 KB.  Per pair T:
+//       phase 4T     group 0 multiplies slab 2T      | group 1 reads slab 2T, issues W(T+1)
+//       phase 4T + 1 group 0 reads slab 2T+1, A(T+2) | group 1 multiplies slab 2T
+//       phase 4T + 2 group 0 multiplies slab 2T+1    | group 1 reads slab 2T+1, issues A(T+2)
+//                    both: vmcnt(4) -- W(T+1), A(T+1) landed, A(T+2) in flight
+//       phase 4T + 3 group 0 reads slab 2T+2, W(T+2) | group 1 multiplies slab 2T+1
+//     The loop is unrolled over 6 pairs (slot indices 3 x 2), every ds_read address is a
+//     base register + immediate.
+// Same k order, same bits.
+// ---------------------------------------------------------------------------
+// Loader state of one tile of the pair-staged ping-pong kernel (all per-lane offsets are
+// bytes relative to the tile's descriptors).
+struct PpLoader {
+  __amdgpu_buffer_rsrc_t srd_a, srd_a2, srd_w, cur_srd;
+  unsigned row_off[4], row_off2[4], voff[4], vb[4];
+  int hw0[4];  // (hi0 << 16) | (wi0 & 0xffff): the row's first input pixel (may be negative)
+  int ia, iw, is_kh, is_kw, is_cin0, seg_soff, cin_limit;
+};
+
+// Persistent workgroups: a workgroup walks tiles q = blockIdx.x, + gridDim.x, ...  After a
+// tile's main loop the first pairs of the NEXT tile -- A(0), W(0), A(1): exactly the kernel's
+// prologue -- are requested before the epilogue runs and land under it; the epilogue stages
+// through the two ring slots the prefetch does not use (A slot 2 + W slot 1: 64 KB).
+// LDS: [A0 32K][A1 32K][W0 32K][A2 32K][W1 32K].
+__device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int tid, bool prefetched,
+                                                  bool has_next, int ntile_m, int ntile_n) {
+  const GemmArgs g = reload_gemm_args();
+  constexpr int BM = 256, BN = 256, BKP = 32, TM = 4, TN = 2;
+  constexpr int SLOTF = BM * BKP;  // floats per 32 KB slot
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  auto a_slot = [&](int sl) { return smem + (sl < 2 ? sl : 3) * SLOTF; };
+  auto w_slot = [&](int sl) { return smem + (sl == 0 ? 2 : 4) * SLOTF; };
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int HoWo = g.Ho * g.Wo;
+  const int np = g.Kp / BKP;  // k-tile pairs
+  const int k1_pairs = g.A2 ? g.K1 / BKP : 0x7fffffff;
+
+  // ---- loader: piece `it` of this wave = rows it * 64 + wave * 8 .. + 7, one 128-B line each
+  auto set_tap = [&](PpLoader& L) {  // per-lane bounds of tap (is_kh, is_kw): once per tap
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int hi = (L.hw0[it] >> 16) + L.is_kh, wi = (int)(short)(L.hw0[it] & 0xffff) + L.is_kw;
+      const bool inb = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.Wd;
+      L.voff[it] = inb ? L.row_off[it] : OOB;
+    }
+    L.seg_soff = (int)((((long)L.is_kh * g.Wd + L.is_kw) * g.a_pix_stride) * 4);
+  };
+  auto setup = [&](PpLoader& L, int tm, int tn) {
+    const int prow = lane >> 3, pos = lane & 7;
+    const int m0 = tm * BM;
+    const int img0 = m0 / HoWo;       // scalar
+    const int rem0 = m0 - img0 * HoWo;
+    // descriptors: A from (image img0, pixel (-pad, -pad)) so that every per-lane offset is
+    // non-negative; W from the tile's first row.  Out-of-range offsets read as zeros.
+    const long bias = ((long)g.pad * g.Wd + g.pad) * g.a_pix_stride;
+    L.srd_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A + (long)img0 * g.a_img_stride - bias), 0, 0x7fffffff, 0x00020000);
+    L.srd_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A2 ? g.A2 + (long)img0 * g.a2_img_stride : g.A), 0, 0x7fffffff,
+        0x00020000);
+    L.srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W + (long)tn * BN * g.Kp), 0,
+                                                0x7fffffff, 0x00020000);
+    // (rows of a tile are consecutive: the per-lane divisions run on rem0 + row < HoWo + 256,
+    // exact in float arithmetic with one correction step -- a tenth of an integer division)
+    const float r_howo = 1.0f / (float)HoWo, r_wo = 1.0f / (float)g.Wo;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 64 + wave * 8 + prow;
+      const int q = pos ^ ((row >> 1) & 7);  // source chunk of this lane's LDS position
+      const bool ok = m0 + row < g.M;
+      const int x = rem0 + (ok ? row : 0);
+      int dimg = (int)((float)x * r_howo);
+      dimg -= (dimg * HoWo > x);
+      dimg += ((dimg + 1) * HoWo <= x);
+      const int rem = x - dimg * HoWo;
+      int ho = (int)((float)rem * r_wo);
+      ho -= (ho * g.Wo > rem);
+      ho += ((ho + 1) * g.Wo <= rem);
+      const int wo = rem - ho * g.Wo;
+      const int hi0 = ho * g.stride - g.pad, wi0 = wo * g.stride - g.pad;
+      L.hw0[it] = (hi0 << 16) | (wi0 & 0xffff);
+      L.row_off[it] = ok ? (unsigned)(((long)dimg * g.a_img_stride +
+                                       ((long)hi0 * g.Wd + wi0) * g.a_pix_stride + bias + q * 4) * 4)
+                         : OOB;
+      L.row_off2[it] = (ok && g.A2)
+                           ? (unsigned)(((long)dimg * g.a2_img_stride +
+                                         ((long)(ho * g.stride2) * g.W2d + wo * g.stride2) *
+                                             g.a2_pix_stride + q * 4) * 4)
+                           : OOB;
+      L.vb[it] = tn * BN + row < g.N ? (unsigned)(((long)row * g.Kp + q * 4) * 4) : OOB;
+    }
+    L.ia = L.iw = L.is_kh = L.is_kw = L.is_cin0 = 0;
+    L.cin_limit = g.Cin;
+    L.cur_srd = L.srd_a;
+    set_tap(L);
+  };
+  // the A rows of pair L.ia into A slot SLOT (`really`: a tile whose first pairs were
+  // prefetched only replays the state changes), then advance
+  auto issue_a = [&](PpLoader& L, auto slot_tag, bool really) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    if (really) {
+      int woff = wave * (8 * BKP);
+      asm volatile("" : "+s"(woff));  // (not sixteen hoisted LDS addresses in scalar registers)
+      float* dst = a_slot(SLOT) + woff;
+      const int soff = L.seg_soff + L.is_cin0 * 4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(L.cur_srd, (LDS_AS void*)(dst + it * (64 * BKP)), 16,
+                                                 L.voff[it], soff, 0, 0);
+    }
+    if (L.ia + 1 < np) {  // past the end the last pair is fetched again (constant vmcnt counts)
+      ++L.ia;
+      L.is_cin0 += BKP;
+      if (L.ia == k1_pairs) {
+        // second source from here on: a 1x1 / stride2 input, always in bounds, k from K1
+        L.cur_srd = L.srd_a2;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) L.voff[it] = L.row_off2[it];
+        L.seg_soff = 0;
+        L.is_cin0 = 0;
+        L.cin_limit = 0x7fffffff;
+      } else if (L.is_cin0 >= L.cin_limit) {
+        L.is_cin0 = 0;
+        if (++L.is_kw == g.KW) { L.is_kw = 0; ++L.is_kh; }
+        set_tap(L);
+      }
+    }
+  };
+  auto issue_w = [&](PpLoader& L, auto slot_tag, bool really) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    if (really) {
+      int woff = wave * (8 * BKP);
+      asm volatile("" : "+s"(woff));
+      float* dst = w_slot(SLOT) + woff;
+      const int soff = L.iw * (BKP * 4);
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(L.srd_w, (LDS_AS void*)(dst + it * (64 * BKP)), 16,
+                                                 L.vb[it], soff, 0, 0);
+    }
+    if (L.iw + 1 < np) ++L.iw;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  PpLoader L;
+  setup(L, tile_m, tile_n);
+
+  // ---- fragments: per lane four chunk positions (slab x hi/lo); one base register set per
+  // slot group a ds_read immediate (< 64 KB) can reach
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  const float* a_p[2][2];  // A slots 0, 1
+  const float* a_q[2][2];  // A slot 2
+  const float* b_p[2][2];  // W slot 0
+  const float* b_q[2][2];  // W slot 1
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+      const int off = ((sl * 4 + fhalf * 2 + hl) ^ fsw) * 4;
+      a_p[sl][hl] = a_slot(0) + (wm * 128 + frow) * BKP + off;
+      a_q[sl][hl] = a_slot(2) + (wm * 128 + frow) * BKP + off;
+      b_p[sl][hl] = w_slot(0) + (wn * 64 + frow) * BKP + off;
+      b_q[sl][hl] = w_slot(1) + (wn * 64 + frow) * BKP + off;
+    }
+  f32x4 ah[TM], al[TM], bh[TN], bl[TN];
+  auto read_frags = [&](auto sa_tag, auto sw_tag, auto slab_tag) {
+    constexpr int SLA = decltype(sa_tag)::value, SLW = decltype(sw_tag)::value;
+    constexpr int SLAB = decltype(slab_tag)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[j] = *reinterpret_cast<const f32x4*>((SLW ? b_q : b_p)[SLAB][0] + j * 32 * BKP);
+      bl[j] = *reinterpret_cast<const f32x4*>((SLW ? b_q : b_p)[SLAB][1] + j * 32 * BKP);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (SLA == 2) {
+        ah[i] = *reinterpret_cast<const f32x4*>(a_q[SLAB][0] + i * 32 * BKP);
+        al[i] = *reinterpret_cast<const f32x4*>(a_q[SLAB][1] + i * 32 * BKP);
+      } else {
+        ah[i] = *reinterpret_cast<const f32x4*>(a_p[SLAB][0] + SLA * SLOTF + i * 32 * BKP);
+        al[i] = *reinterpret_cast<const f32x4*>(a_p[SLAB][1] + SLA * SLOTF + i * 32 * BKP);
+      }
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto multiply = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(ah[i]), as_f16x8(bl[j]),
+                                                           acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(al[i]), as_f16x8(bh[j]),
+                                                           acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(ah[i]), as_f16x8(bh[j]),
+                                                           acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // read phase of the even slab of the pair in slots (SLA, SLW): fragments, then the W rows
+  // of the NEXT pair into the other W slot
+  auto read_even = [&](auto sa_tag, auto sw_tag) {
+    constexpr int SLW = decltype(sw_tag)::value;
+    read_frags(sa_tag, sw_tag, I0{});
+    issue_w(L, std::integral_constant<int, SLW ^ 1>{}, true);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // ... of the odd slab: fragments, then the A rows of the pair two ahead (the A slot that
+  // held the previous pair)
+  auto read_odd = [&](auto sa_tag, auto sw_tag) {
+    constexpr int SLA = decltype(sa_tag)::value;
+    read_frags(sa_tag, sw_tag, I1{});
+    issue_a(L, std::integral_constant<int, (SLA + 2) % 3>{}, true);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // prologue: A(0), W(0), A(1) in flight (or already here: prefetched by the previous tile,
+  // which also waited for them); A(0), W(0) landed
+  issue_a(L, I0{}, !prefetched);
+  issue_w(L, I0{}, !prefetched);
+  issue_a(L, I1{}, !prefetched);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  phase_barrier();
+  int left = np;
+  if (wm == 0) {
+    read_even(I0{}, I0{});
+    phase_barrier();
+    auto pair = [&](auto sa_tag, auto sw_tag) {
+      constexpr int SLA = decltype(sa_tag)::value, SLW = decltype(sw_tag)::value;
+      multiply();
+      phase_barrier();
+      read_odd(sa_tag, sw_tag);
+      phase_barrier();
+      multiply();
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      phase_barrier();
+      read_even(std::integral_constant<int, (SLA + 1) % 3>{}, std::integral_constant<int, SLW ^ 1>{});
+      phase_barrier();
+    };
+    for (;;) {
+      pair(std::integral_constant<int, 0>{}, I0{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 1>{}, I1{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 2>{}, I0{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 0>{}, I1{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 1>{}, I0{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 2>{}, I1{});
+      if (--left == 0) break;
+    }
+  } else {
+    phase_barrier();
+    auto pair = [&](auto sa_tag, auto sw_tag) {
+      read_even(sa_tag, sw_tag);
+      phase_barrier();
+      multiply();
+      phase_barrier();
+      read_odd(sa_tag, sw_tag);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      phase_barrier();
+      multiply();
+      phase_barrier();
+    };
+    for (;;) {
+      pair(std::integral_constant<int, 0>{}, I0{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 1>{}, I1{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 2>{}, I0{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 0>{}, I1{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 1>{}, I0{});
+      if (--left == 0) break;
+      pair(std::integral_constant<int, 2>{}, I1{});
+      if (--left == 0) break;
+    }
+  }
+  // the re-fetched tail pairs have landed and every wave is done with the ring
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (has_next) {
+    // the next tile's prologue, requested now; its loader state is rebuilt after the epilogue
+    // (keeping it alive across the epilogue would cost 20 vector registers there)
+    PpLoader N;
+    setup(N, ntile_m, ntile_n);
+    issue_a(N, I0{}, true);
+    issue_w(N, I0{}, true);
+    issue_a(N, I1{}, true);
+  }
+  const GemmArgs ge = reload_gemm_args();  // the epilogue's arguments, loaded here
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * ge.acc_scale;
+  // staging: A slot 2 + W slot 1 (contiguous 64 KB; the prefetch goes to A0, A1, W0)
+  run_epilogue<TM, TN, true>(ge, acc, a_slot(2), wave, lane, tile_m * BM + wm * 128,
+                             tile_n * BN + wn * 64);
+}
+
+__global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, int tiles_m,
+                                                                    int tiles_n) {
+  const int T = tiles_m * tiles_n;
+  int q = blockIdx.x;
+  if (q >= T) return;
+  bool prefetched = false;
+  for (;;) {
+    const int tile = xcd_tile(q, T);
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const bool has_next = q + (int)gridDim.x < T;
+    int ntile_m = tile_m, ntile_n = tile_n;
+    if (has_next) {
+      const int nt = xcd_tile(q + gridDim.x, T);
+      ntile_m = nt / tiles_n;
+      ntile_n = nt - ntile_m * tiles_n;
+    }
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    split16_pp32_tile(tile_m, tile_n, tid, prefetched, has_next, ntile_m, ntile_n);
+    if (!has_next) break;
+    // the prefetch has landed, the epilogue's stores are out and its staging reads are done
+    // before the next tile's DMA reuses the slots
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    q += gridDim.x;
+    prefetched = true;
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void igemm_split16_pp_kernel(GemmArgs g, int tiles_m,
                                                                   int tiles_n) {
   // one tile per workgroup (gridDim.x == tiles), or workgroups walking tiles q = blockIdx.x,
@@ -2028,6 +2400,40 @@ static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
 }
 
 // the ping-pong form of the 256 x 256 tile (4-slot ring: 128 KB of LDS)
+// ... staged in k-tile pairs (whole 128-byte lines): A ring 3 x 32 KB + W ring 2 x 32 KB
+static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+  const size_t lds = size_t(5) * 256 * 32 * sizeof(float);
+  auto kern = igemm_split16_pp32_kernel;
+  int dev = 0;
+  MILAN_CHECK_HIP(hipGetDevice(&dev));
+  static std::vector<char> attr_set(64, 0);
+  if (dev < 64 && !attr_set[dev]) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dev] = 1;
+  }
+  // more tiles than CUs: persistent workgroups (a multiple of 8, so a workgroup's tiles stay
+  // on its XCD), the next tile's first pairs prefetched under the epilogue
+  static std::vector<int> cus(64, 0);
+  if (dev < 64 && !cus[dev]) {
+    int n = 0;
+    MILAN_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus[dev] = n < 8 ? 8 : n / 8 * 8;
+  }
+  int grid = tiles_m * tiles_n;
+  // MILAN_PP_PERSIST=1: persistent workgroups with the next tile's first pairs prefetched
+  // under the epilogue.  Measured (same-box A/B, profiles/r4_experiments.txt B): 1166 -> 1160
+  // neurons/s, layer3 112.0 -> 112.9 ms -- the static tile assignment costs more than the
+  // 12-piece prologue it hides; one tile per workgroup (hardware dispatch) is the default.
+  static int persist = -1;
+  if (persist < 0) { const char* e = getenv("MILAN_PP_PERSIST"); persist = e ? atoi(e) : 0; }
+  if (persist && dev < 64 && grid > cus[dev]) grid = cus[dev];
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g, tiles_m, tiles_n);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static int launch_split16_pp(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
   const size_t lds = size_t(4) * (256 + 256) * 16 * sizeof(float);
@@ -2065,7 +2471,13 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
   if constexpr (BM == 256 && BN == 256 && STAGES == 5) {
     static int pp = -1;  // MILAN_PP=0: the round-3 lockstep kernels (same bits; A/B timing)
     if (pp < 0) { const char* e = getenv("MILAN_PP"); pp = e ? atoi(e) : 1; }
-    if (pp && !g.chunk_major && pp_eligible(g)) return launch_split16_pp(g, s);
+    if (pp && !g.chunk_major && pp_eligible(g)) {
+      // pp == 2: the 16-slot form everywhere (A/B timing)
+      if (pp != 2 && g.Cin % 32 == 0 && (!g.A2 || g.K1 % 32 == 0) &&
+          ((long)g.H + g.pad) < 32768 && ((long)g.Wd + g.pad) < 32768)
+        return launch_split16_pp32(g, s);
+      return launch_split16_pp(g, s);
+    }
   }
 #if MILAN_EXPERIMENTS
   static int shape = -1;
