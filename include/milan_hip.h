@@ -30,6 +30,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the prototypes of this header
+ * are its whole dynamic symbol table (tests/test_host.py checks `nm -D`). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #define MILAN_ABI_VERSION 6
 
 enum {
@@ -438,6 +444,10 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       int kh, int kw, int stride, int pad, int relu,
                       const float* residual, float* y, int precision,
                       milan_stream stream);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

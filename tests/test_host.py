@@ -42,6 +42,12 @@ def test_library_exports_every_header_symbol():
     exported = sorted(
         set(re.findall(r' T (milan_[a-z0-9_]+)$', out, flags=re.M)))
     assert exported == syms, 'undocumented or missing C-ABI exports'
+    # -fvisibility=hidden: no C++ internals (launchers, StageScope, ...) in the
+    # dynamic symbol table -- every defined function symbol is a C entry point
+    functions = re.findall(r' [TW] (\S+)$', out, flags=re.M)
+    stray = sorted(f for f in functions if f not in syms
+                   and f not in ('_init', '_fini'))
+    assert not stray, f'internal symbols exported: {stray[:5]}'
 
 
 def test_dims_struct_matches_header_layout():
