@@ -54,24 +54,78 @@ namespace {
 
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-// 8 fp32 -> (hi, lo) f16x8 pair, hi saturating (same roundings as gemm.hip)
-__device__ inline void chain_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
-  f16x8 h, l;
+// 16 bytes from (uniform base) + (per-lane byte offset)
+__device__ __forceinline__ f32x4 asm_load16(const float* base, unsigned off) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+  return v;
+}
+
+// float(h.f16[sel]) + float(l.f16[sel]) in one instruction (both conversions are exact:
+// the bits of (float)h + (float)l)
+template <int SEL>
+__device__ __forceinline__ float mix_add(float hpair, float lpair) {
+  float r;
+  if constexpr (SEL == 0)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hpair), "v"(lpair));
+  else
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hpair), "v"(lpair));
+  return r;
+}
+// x - float(h.f16[sel])
+template <int SEL>
+__device__ __forceinline__ float mix_sub(float x, float hpair) {
+  float r;
+  if constexpr (SEL == 0)
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  else
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float cvt_pk(float a, float b) {  // (f16(a), f16(b)), RNE
+  float r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// 8 values already clamped to [0, 65504] -> (hi, lo) f16x8 pair: the roundings of
+// chain_split8 in 12 instructions instead of 32
+__device__ __forceinline__ void split8_fast(const float* x, f32x4* hi_out, f32x4* lo_out) {
+  f32x4 hi, lo;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    l[e] = (_Float16)(x - (float)hh);
+  for (int d = 0; d < 4; ++d) {
+    hi[d] = cvt_pk(x[2 * d], x[2 * d + 1]);
+    lo[d] = cvt_pk(mix_sub<0>(x[2 * d], hi[d]), mix_sub<1>(x[2 * d + 1], hi[d]));
   }
-  *hi_out = __builtin_bit_cast(f32x4, h);
-  *lo_out = __builtin_bit_cast(f32x4, l);
+  *hi_out = hi;
+  *lo_out = lo;
+}
+__device__ __forceinline__ float clamp_relu(float u) {  // min(max(u, 0), 65504)
+  float r;
+  asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(u), "v"(65504.f));
+  return r;
+}
+
+// 8 fp32 -> (hi, lo) f16x8 pair, hi saturating (same roundings as gemm.hip's split8)
+__device__ inline void chain_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
+  f32x4 hi, lo;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float x0, x1;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(v[2 * d]), "v"(-65504.f), "v"(65504.f));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(v[2 * d + 1]), "v"(-65504.f), "v"(65504.f));
+    hi[d] = cvt_pk(x0, x1);
+    lo[d] = cvt_pk(mix_sub<0>(x0, hi[d]), mix_sub<1>(x1, hi[d]));
+  }
+  *hi_out = hi;
+  *lo_out = lo;
 }
 
 __device__ inline void chain_join8(f32x4 hi, f32x4 lo, float* v) {
-  const f16x8 h = h8(hi), l = h8(lo);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (float)h[e] + (float)l[e];
+  for (int d = 0; d < 4; ++d) {
+    v[2 * d] = mix_add<0>(hi[d], lo[d]);
+    v[2 * d + 1] = mix_add<1>(hi[d], lo[d]);
+  }
 }
 
 constexpr int kSRow = 68;        // floats per row of a wave's LDS strip (64 + 4)
@@ -503,6 +557,365 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   }
 }
 
+// ---- planes 256 (layer3): 128 pixels per workgroup, TWO waves per SIMD --------------
+// The one-wave form above needs ~400 registers for a wave's 32 pixels (t2 fragments 128 +
+// reduce accumulators 128 + ...).  Here the two waves (p, 0) and (p, 1) of a SIMD share
+// pixel block p and halve both big register sets:
+//   expand  K-split: wave (p, 0) holds the t2 fragments of k 0..127, wave (p, 1) those
+//           of k 128..255.  (p, 0) starts slab s from zero over its half and HANDS the
+//           accumulator over through LDS; one step later (p, 1) loads it and finishes
+//           the slab over its half -- one accumulator, k ascending, i.e. the bits of the
+//           unfused kernel -- while (p, 0) is already on slab s + 1;
+//   reduce  channel-split: (p, h) accumulates output channels 128 h .. 128 h + 127.
+// Step s = 0..16, all eight waves in lockstep (one barrier per weight-tile pair):
+//   A  (p,0): E1(slab s) -> hand-over        (p,1): E2(slab s-1) -> raw strip
+//   B  both:  epilogue of slab s-1, 16 rows x 64 channels each (whole 256-byte row
+//             segments): scale, + bias, + residual, ReLU, split -> HBM and -> strip
+//   C  both:  reduce over slab s-1 (x' fragments from the strip) into their 128 channels
+// Weights stream as PAIRS of 16 KB tiles (the tile of the h = 0 waves and the tile of the
+// h = 1 waves; 24 MFMAs per wave per pair) through a ring of three pairs; LDS = ring
+// 96 KB + strips 32 KB (XOR-swizzled, unpadded) + hand-over 32 KB = all 160 KB.
+// Residual / bias loads are issued by inline asm so that the compiler does not drain
+// the weight stream in front of their first use; the counted waits below cover them.
+template <bool PROF>
+__global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
+  // in-kernel phase profile (experiments: ChainArgs::prof): cycles of wave 0 / wave 4 in
+  // 0 prologue, 1 DMA issue, 2 expand MFMAs, 3 hand-over / strip, 4 reduce MFMAs, 5 counted
+  // wait + barrier, 6 epilogue B, 7 final epilogue
+  long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0;
+  auto stamp = [&](int k) {
+    if constexpr (PROF) {
+      const long long t = __builtin_readcyclecounter();
+      tprof[k] += t - tlast;
+      tlast = t;
+    }
+  };
+  if constexpr (PROF) tlast = __builtin_readcyclecounter();
+  constexpr int P = 256, N3 = 1024, N1 = 256, NSLAB = 16;
+  constexpr int NIT = 4 * (NSLAB + 1);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = wave & 3, h = wave >> 2;
+  const int px = lane & 31, half = lane >> 5;
+  float* ring = smem;                                   // [6][16 KB]
+  float* strip = smem + 6 * kTileFloats + p * 2048;     // 32 px x 64 channels
+  float* hand = smem + 6 * kTileFloats + 4 * 2048 + p * 2048;
+
+  const long m0 = (long)blockIdx.x * 128 + p * 32;      // pixel block's first pixel
+  const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
+  const bool tail = (long)(blockIdx.x + 1) * 128 > g.M;  // workgroup-uniform
+
+  // ---- weight-pair DMA: this wave moves 4 of the 16 pieces of tile h of the pair ------
+  // piece i of a wave = rows 16 i + 4 (wave & 3) .. + 3 of the tile: the swizzle term
+  // (row & 15) is the same for the four pieces, so ONE per-lane offset per matrix serves
+  // all of them and the rest of the address is scalar (buffer_load ... lds: descriptor +
+  // VGPR offset + SGPR offset; no vector ALU in the issue path)
+  const int lrow = lane >> 4, lpos = lane & 15;
+  const int wrow = 4 * (wave & 3) + lrow;                // row within a 16-row group
+  const unsigned voff3 = (unsigned)((wrow * P + ((lpos ^ wrow) << 2)) * 4);
+  const unsigned voff1 = (unsigned)((wrow * N3 + ((lpos ^ wrow) << 2)) * 4);
+  const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.W3), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.W1), 0, 0x7fffffff, 0x00020000);
+  auto issue_pair = [&](int q) {
+    q = q < NIT ? q : NIT - 1;
+    const int s = q >> 2, it = q & 3;
+    float* dst = ring + ((q % 3) * 2 + h) * kTileFloats + (wave & 3) * 256;
+    if (it < 2) {
+      int sl = h == 0 ? s : s - 1;
+      sl = sl < 0 ? 0 : (sl > NSLAB - 1 ? NSLAB - 1 : sl);
+      const int soff = ((64 * sl) * P + 128 * h + 64 * it) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd3, (LDS_AS void*)(dst + i * 1024), 16, voff3,
+                                                 soff + i * (16 * P * 4), 0, 0);
+    } else {
+      const int sl = s < 1 ? 0 : s - 1;
+      const int soff = ((128 * h + 64 * (it - 2)) * N3 + 64 * sl) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd1, (LDS_AS void*)(dst + i * 1024), 16, voff1,
+                                                 soff + i * (16 * N3 * 4), 0, 0);
+    }
+  };
+
+  // ---- prologue --------------------------------------------------------------------
+  f32x4 t2h[8], t2l[8];
+  {
+    const float* tp = g.T2 + mfrag * P + 128 * h + half * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      t2h[s] = *reinterpret_cast<const f32x4*>(tp + s * 16);
+      t2l[s] = *reinterpret_cast<const f32x4*>(tp + s * 16 + 4);
+    }
+  }
+  // row-major epilogue roles: 8 lanes cover the 64 channels of a row, 8 rows per pass;
+  // this wave owns rows 16 h .. 16 h + 15 of the block
+  const int erow = lane >> 3, ecol = (lane & 7) * 8;
+  f32x4 res[2][2], bias3v[2];
+  // per-lane byte offsets of its two epilogue rows within the workgroup's 128 rows of X / R
+  // (clamped to the last valid row in the tail workgroup; stores are masked there)
+  const long wg_m0 = (long)blockIdx.x * 128;
+  unsigned eoff[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    long r = p * 32 + 16 * h + 8 * ps + erow;
+    r = wg_m0 + r < g.M ? r : (long)g.M - 1 - wg_m0;
+    eoff[ps] = (unsigned)((r * N3 + ecol) * 4);
+  }
+  const float* rbase = g.R + wg_m0 * N3;
+  float* xbase = g.X + wg_m0 * N3;
+  auto load_res = [&](int j) {
+    j = j < NSLAB ? j : NSLAB - 1;
+    bias3v[0] = asm_load16(g.bias3 + 64 * j, (unsigned)(ecol * 4));
+    bias3v[1] = asm_load16(g.bias3 + 64 * j + 4, (unsigned)(ecol * 4));
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      res[ps][0] = asm_load16(rbase + 64 * j, eoff[ps]);
+      res[ps][1] = asm_load16(rbase + 64 * j + 4, eoff[ps]);
+    }
+  };
+  load_res(0);
+  issue_pair(0);
+  issue_pair(1);
+
+  f32x16 acc1[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[u][r] = 0.f;
+
+  const int fsw = px & 15;
+  // The swizzled LDS addresses are loop-invariant, and there are ~40 of them: left to
+  // itself the compiler keeps them all in registers (and spills).  An opaque copy of the
+  // swizzle term at each use site makes it recompute them (one v_xad_u32 per access).
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto wfrag = [&](const float* slot, int sw, int t, int c) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(slot + (32 * t + px) * 64 + ((c ^ sw) << 2));
+  };
+  // weight fragments of k-step s4 of the wave's tile: [hi, lo] of MFMA tile 0, then of
+  // tile 1; double buffered (the reads of step s4 + 1 fly under step s4's MFMAs)
+  f32x4 wf[2][4];
+  auto load_w = [&](const float* slot, int s4, int buf) {
+    const int sw = opaque(fsw);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      wf[buf][2 * t] = wfrag(slot, sw, t, 4 * s4 + 2 * half);
+      wf[buf][2 * t + 1] = wfrag(slot, sw, t, 4 * s4 + 2 * half + 1);
+    }
+  };
+  // swizzled 32 x 64 strip: row r keeps its 16-byte chunk c at position c ^ (r & 15)
+  auto to_strip = [&](float* st, const f32x16& a, int t) {
+    const int sw = opaque(fsw);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      f32x4 v = {a[4 * qd], a[4 * qd + 1], a[4 * qd + 2], a[4 * qd + 3]};
+      *reinterpret_cast<f32x4*>(st + px * 64 + (((8 * t + 2 * qd + half) ^ sw) << 2)) = v;
+    }
+  };
+  auto row_chunk = [&](float* st, int row, int c) -> float* {
+    return st + row * 64 + ((c ^ opaque(row & 15)) << 2);
+  };
+
+  wait_vmcnt<4>();   // t2, residual, bias, pair 0 have landed; pair 1 may fly
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(t2h[s]), "+v"(t2l[s]));
+  asm volatile("" : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1]),
+                    "+v"(bias3v[0]), "+v"(bias3v[1]));
+
+  stamp(0);
+  for (int s = 0; s <= NSLAB; ++s) {
+    const bool expand_on = h == 0 ? s < NSLAB : s >= 1;
+    f32x16 acc3[2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = 4 * s + it;
+      // (the h = 0 waves issue their DMA pieces ahead of the MFMAs, the h = 1 waves behind
+      // them: eight waves issuing at once queue up at the CU's one LDS-DMA path)
+      if (h == 0) issue_pair(q + 2);
+      stamp(1);
+      const float* slot = ring + ((q % 3) * 2 + h) * kTileFloats;
+      if (it < 2) {
+        // ---- A: this wave's half of the expand product --------------------------------
+        if (it == 0) {
+          // (defined on every path: the accumulator must not be live across B and C)
+          if (h == 0 || !expand_on) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
+          } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(hand + ((4 * t + i) * 64 + lane) * 4);
+                acc3[t][4 * i] = v[0]; acc3[t][4 * i + 1] = v[1];
+                acc3[t][4 * i + 2] = v[2]; acc3[t][4 * i + 3] = v[3];
+              }
+          }
+        }
+        if (expand_on) {
+          load_w(slot, 0, 0);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const int ks = 4 * it + s4, b = s4 & 1;
+            if (s4 < 3) load_w(slot, s4 + 1, b ^ 1);
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s4 == 1 && h == 1) { issue_pair(q + 2); __builtin_amdgcn_sched_barrier(0); }
+          }
+          stamp(2);
+          if (it == 1) {
+            if (h == 0) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const f32x4 v = {acc3[t][4 * i], acc3[t][4 * i + 1], acc3[t][4 * i + 2], acc3[t][4 * i + 3]};
+                  *reinterpret_cast<f32x4*>(hand + ((4 * t + i) * 64 + lane) * 4) = v;
+                }
+            } else {
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                acc3[t] = acc3[t] * g.scale3;
+                to_strip(strip, acc3[t], t);
+              }
+            }
+          }
+        } else if (h == 1) {
+          issue_pair(q + 2);   // (step 0: nothing to finish yet; the pieces are still issued)
+        }
+      } else if (s >= 1) {
+        // ---- C: reduce over slab s - 1, output rows 128 h + 64 (it - 2) .. ------------------
+        const int u0 = 2 * (it - 2);
+        f32x4 xh[4], xl[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const float* fp = strip + px * 64;
+          const int sw = opaque(fsw);
+          xh[s4] = *reinterpret_cast<const f32x4*>(fp + (((4 * s4 + 2 * half) ^ sw) << 2));
+          xl[s4] = *reinterpret_cast<const f32x4*>(fp + (((4 * s4 + 2 * half + 1) ^ sw) << 2));
+        }
+        load_w(slot, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int b = s4 & 1;
+          if (s4 < 3) load_w(slot, s4 + 1, b ^ 1);
+          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xh[s4]), acc1[u0], 0, 0, 0);
+          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xh[s4]), acc1[u0 + 1], 0, 0, 0);
+          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xl[s4]), acc1[u0], 0, 0, 0);
+          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xl[s4]), acc1[u0 + 1], 0, 0, 0);
+          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xh[s4]), acc1[u0], 0, 0, 0);
+          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xh[s4]), acc1[u0 + 1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s4 == 1 && h == 1) { issue_pair(q + 2); __builtin_amdgcn_sched_barrier(0); }
+        }
+      } else if (h == 1) {
+        issue_pair(q + 2);   // (no reduce in step 0: the pieces are still issued)
+      }
+      stamp(it < 2 ? 3 : 4);
+      // Pair q + 1 must have landed.  VMEM ops younger than its pieces: the four pieces
+      // of pair q + 2 -- and, at the first iteration after an epilogue, that epilogue's
+      // four stores and six loads (stores may retire early: they are not counted on).
+      if (tail) wait_vmcnt<0>();
+      else if (it == 2 && s >= 1) wait_vmcnt<10>();
+      else wait_vmcnt<4>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stamp(5);
+      if (it == 1 && s >= 1) {
+        // ---- B: epilogue of slab s - 1, rows 16 h .. 16 h + 15 of the block ---------------
+        // (the residual / bias registers were loaded one step ago: older than everything
+        // the last counted wait let fly)
+        asm volatile("" : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1]),
+                          "+v"(bias3v[0]), "+v"(bias3v[1]));
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int row = 16 * h + 8 * ps + erow;
+          const long m = m0 + row;
+          float* sp0 = row_chunk(strip, row, 2 * (lane & 7));
+          float* sp1 = row_chunk(strip, row, 2 * (lane & 7) + 1);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp0);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp1);
+          float v[8];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            v[2 * d] = clamp_relu(v0[2 * d] + bias3v[0][2 * d] + mix_add<0>(res[ps][0][d], res[ps][1][d]));
+            v[2 * d + 1] = clamp_relu(v0[2 * d + 1] + bias3v[0][2 * d + 1] + mix_add<1>(res[ps][0][d], res[ps][1][d]));
+            v[4 + 2 * d] = clamp_relu(v1[2 * d] + bias3v[1][2 * d] + mix_add<0>(res[ps][0][2 + d], res[ps][1][2 + d]));
+            v[5 + 2 * d] = clamp_relu(v1[2 * d + 1] + bias3v[1][2 * d + 1] + mix_add<1>(res[ps][0][2 + d], res[ps][1][2 + d]));
+          }
+          f32x4 hi, lo;
+          split8_fast(v, &hi, &lo);
+          if (m < g.M) {
+            float* xp = xbase + 64 * (s - 1) + (eoff[ps] >> 2);
+            *reinterpret_cast<f32x4*>(xp) = hi;
+            *reinterpret_cast<f32x4*>(xp + 4) = lo;
+          }
+          *reinterpret_cast<f32x4*>(sp0) = hi;
+          *reinterpret_cast<f32x4*>(sp1) = lo;
+        }
+        load_res(s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stamp(6);
+      }
+    }
+  }
+  wait_vmcnt<0>();  // dummy pairs drained before the ring becomes the staging area
+  __builtin_amdgcn_s_barrier();
+
+  // ---- reduce epilogue: t1' = relu(acc1 * scale + bias) in split form --------------
+  float* fstrip = ring + wave * 2048;
+#pragma unroll
+  for (int cidx = 0; cidx < 2; ++cidx) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      acc1[2 * cidx + t] = acc1[2 * cidx + t] * g.scale1;
+      to_strip(fstrip, acc1[2 * cidx + t], t);
+    }
+    const int n = 128 * h + 64 * cidx + ecol;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + n);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + n + 4);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = ps * 8 + erow;
+      const long m = m0 + row;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row_chunk(fstrip, row, 2 * (lane & 7)));
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(row_chunk(fstrip, row, 2 * (lane & 7) + 1));
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = clamp_relu(v0[e] + b0[e]);
+        v[4 + e] = clamp_relu(v1[e] + b1[e]);
+      }
+      f32x4 hi, lo;
+      split8_fast(v, &hi, &lo);
+      if (m < g.M) {
+        float* tp = g.T1 + m * N1 + n;
+        *reinterpret_cast<f32x4*>(tp) = hi;
+        *reinterpret_cast<f32x4*>(tp + 4) = lo;
+      }
+    }
+  }
+  if constexpr (PROF) {
+    stamp(7);
+    if (lane == 0 && (wave == 0 || wave == 4) && g.prof)
+      for (int k = 0; k < 8; ++k) g.prof[((long)blockIdx.x * 2 + h) * 8 + k] = tprof[k];
+  }
+}
+
 // (Round 3 also built a producer / consumer form for P = 256 -- expand waves holding t2
 // and issuing all DMA, reduce waves running the epilogue and S3 one slab behind, one of
 // each per SIMD.  Bitwise correct, 8.6 ms per layer3 block pair against 7.5 ms for the
@@ -537,6 +950,17 @@ static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
   return 0;
 }
 
+static int launch_chainw(const ChainArgs& a, hipStream_t s) {
+  constexpr int lds = 160 * 1024;
+  // (per launch: the attribute is per device, and a process may drive several)
+  auto kern = a.prof ? chainw_kernel<true> : chainw_kernel<false>;
+  MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(512), lds, s, a);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_chain(const ChainArgs& a, hipStream_t s) {
   const int NR = a.NR ? a.NR : a.P;
   MILAN_REQUIRE(chain_supported(a.P, a.KD, NR) && a.M > 0, MILAN_ERR_SHAPE,
@@ -551,8 +975,10 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
       2.0 * M * (4 * P) * (K3 + R1),
       4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * R1 + 4 * P * (K3 + R1)), s);
   int r;
-  if (a.P == 256 && a.prof) r = launch_chain_cfg<256, 4, true, 0, false, true>(a, s);
-  else if (a.P == 256) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
+  static const bool one_wave = getenv("MILAN_CHAIN_WIDE_ONEWAVE") != nullptr;
+  if (a.P == 256 && a.prof && one_wave) r = launch_chain_cfg<256, 4, true, 0, false, true>(a, s);
+  else if (a.P == 256 && one_wave) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
+  else if (a.P == 256) r = launch_chainw(a, s);
   else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);
   // the 128-channel reduce conv runs on the single-accumulator kernel when unfused
   else if (NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128>(a, s);

@@ -1,5 +1,5 @@
 // bitwise check + timing of launch_chain against the two separate launches (scratch)
-#include "../neuron-descriptions_amd/csrc/common.h"
+#include "../../neuron-descriptions_amd/csrc/common.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,18 +58,23 @@ int main(int argc, char** argv) {
   const long dx = diff(X, Xr, (size_t)M * N3), dt = diff(T1, T1r, (size_t)M * P);
   printf("P=%d M=%ld: X mismatches %ld / %ld, T1 mismatches %ld / %ld\n", P, M, dx, M * N3, dt, M * P);
   if (getenv("CHAIN_PROF")) {
+    // chainw_kernel: 8 counters for wave 0 and for wave 4 of every workgroup
     const long nwg = (M + 127) / 128;
-    long long* pr; CK(hipMalloc((void**)&pr, nwg * 64)); CK(hipMemset(pr, 0, nwg * 64));
+    long long* pr; CK(hipMalloc((void**)&pr, nwg * 128)); CK(hipMemset(pr, 0, nwg * 128));
     c.prof = pr; launch_chain(c, 0); CK(hipDeviceSynchronize()); c.prof = nullptr;
-    std::vector<long long> h(nwg * 8); CK(hipMemcpy(h.data(), pr, nwg * 64, hipMemcpyDeviceToHost));
-    double sum[8] = {0}; for (long i = 0; i < nwg; ++i) for (int k = 0; k < 8; ++k) sum[k] += h[i * 8 + k];
-    const char* nm[8] = {"prologue", "issue_tile", "mfma", "s2", "vmcnt wait", "barrier", "final epilogue", "-"};
-    double tot = 0; for (int k = 0; k < 7; ++k) tot += sum[k];
-    for (int k = 0; k < 7; ++k) printf("  %-16s %10.0f cycles/WG  %5.1f%%\n", nm[k], sum[k] / nwg, 100 * sum[k] / tot);
-    printf("  total %.0f cycles/WG\n", tot / nwg);
+    std::vector<long long> h(nwg * 16); CK(hipMemcpy(h.data(), pr, nwg * 128, hipMemcpyDeviceToHost));
+    const char* nm[8] = {"prologue", "dma issue", "expand mfma", "hand-over/strip", "reduce mfma", "wait+barrier", "epilogue B", "final epilogue"};
+    for (int w = 0; w < 2; ++w) {
+      double sum[8] = {0}; for (long i = 0; i < nwg; ++i) for (int k = 0; k < 8; ++k) sum[k] += h[(i * 2 + w) * 8 + k];
+      double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
+      printf(" wave %d:", 4 * w);
+      for (int k = 0; k < 8; ++k) printf(" %s %.0f", nm[k], sum[k] / nwg);
+      printf(" | total %.0f cycles/WG\n", tot / nwg);
+    }
   }
   if (reps > 1) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); float ms;
+    for (int r = 0; r < 3; ++r) { launch_gemm(g3, 0); launch_gemm(g1, 0); launch_chain(c, 0); }
     hipEventRecord(a, 0); for (int r = 0; r < reps; ++r) { launch_gemm(g3, 0); launch_gemm(g1, 0); } hipEventRecord(b, 0); hipEventSynchronize(b);
     hipEventElapsedTime(&ms, a, b); printf("  separate: %.3f ms per pair\n", ms / reps);
     hipEventRecord(a, 0); for (int r = 0; r < reps; ++r) launch_chain(c, 0); hipEventRecord(b, 0); hipEventSynchronize(b);
