@@ -124,6 +124,12 @@ int milan_create(milan_ctx** out, int device, const milan_dims* dims) {
   milan_ctx* c = new milan_ctx();
   c->device = device;
   c->d = d;
+  if (const char* e = getenv("MILAN_ACT_SCALE_LOG2")) {
+    // activation scale of the split-f16 trunk (common.h, milan_ctx::act_scale); 0 = none
+    int k = atoi(e);
+    k = k < 0 ? 0 : (k > 10 ? 10 : k);
+    c->act_scale = ldexpf(1.f, k);
+  }
   int r = dev_alloc(c, (void**)&c->zero, 256);
   if (r == 0) {
     hipError_t e = hipMemset(c->zero, 0, 256);

@@ -936,13 +936,7 @@ static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * (size_t)((RES_LDS ? 7 : 4) * kTileFloats +
                                               NW * 32 * kSRow + (RES_LDS ? 4 * P : 0));
   auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF, NR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-    attr_set = true;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   const int rows = NW * 32;
   const int grid = (a.M + rows - 1) / rows;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
@@ -952,10 +946,8 @@ static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
 
 static int launch_chainw(const ChainArgs& a, hipStream_t s) {
   constexpr int lds = 160 * 1024;
-  // (per launch: the attribute is per device, and a process may drive several)
   auto kern = a.prof ? chainw_kernel<true> : chainw_kernel<false>;
-  MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(512), lds, s, a);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;

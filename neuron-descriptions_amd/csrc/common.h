@@ -116,6 +116,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t s);
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
                         long rows, int K, float scale, hipStream_t s);
 int gemm_profile_enable(int enable);
+// per-device launch state (gemm.hip): dynamic-LDS opt-in of a kernel, CU count in octets
+int ensure_lds_attr(const void* kern, int bytes);
+int device_cus8(int* out);
 void* gemm_profile_begin(double flops, double bytes, hipStream_t s);
 void gemm_profile_end(void* rec, hipStream_t s);
 
@@ -237,6 +240,7 @@ struct ConvW {
   float* ws3 = nullptr;   // 3x3 only, experiments build: ws re-ordered chunk-major (gemm.hip)
   float ws_inv = 1.f;     // exact power of two
   float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
+  float* bias_s = nullptr;  // bias x activation scale (split-f16 trunk, see milan_ctx::act_scale)
   int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;
   int cin_real = 0;  // channels before padding to a multiple of 4
 };
@@ -305,6 +309,17 @@ struct milan_ctx {
   milan::ConvW stem_pair;  // split-f16 stem over pixel-pair groups (encoder.hip)
   milan::ConvW alex[5];    // 'alexnet' config: features.0/3/6/8/10
   float *bn1_scale = nullptr, *bn1_shift = nullptr;
+  // Split-f16 trunk: every activation tensor in split format is stored as x * act_scale
+  // (an exact power of two; MILAN_ACT_SCALE_LOG2, default 5).  `lo = f16(x - f16(x))`
+  // leaves the f16 normal range for |x| < 0.125, and its absolute floor (2^-24) then
+  // costs accuracy relative to x; stored 32 x larger, the same happens only below 0.004,
+  // while `hi` saturates at 2047 instead of 65504.  Scaling by a power of two commutes
+  // with every fp32 operation of the epilogues, so the only places that know about it
+  // are: the stem's folded bn1 (scale, shift) and every conv's folded bias (pre-multiplied
+  // copies below / ConvW::bias_s), and the consumers that leave the split domain (the
+  // mask-weighted pooling and the spatial read-out divide by it).
+  float act_scale = 32.f;
+  float *bn1_scale_s = nullptr, *bn1_shift_s = nullptr;
   std::vector<milan::Bottleneck> blocks[4];
   float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   // decoder

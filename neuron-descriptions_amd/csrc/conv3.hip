@@ -313,20 +313,9 @@ int launch_conv3_p64(const Conv3Args& a0, hipStream_t s) {
                 MILAN_ERR_ARG, "conv3: missing operand");
   a.tiles_y = (a.h + kTR - 1) / kTR;
   a.tiles_x = (a.w + kTC - 1) / kTC;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    MILAN_CHECK_HIP(hipGetDevice(&dev));
-    MILAN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    cus = cus < 8 ? 8 : cus / 8 * 8;
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_p64_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kLds));
-    attr_set = true;
-  }
+  int cus = 0;
+  MILAN_TRY(device_cus8(&cus));
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(conv3_p64_kernel), (int)kLds));
   const double px = (double)a.n * a.h * a.w;
   void* rec = gemm_profile_begin(2.0 * px * 64 * 576, 4.0 * (px * 64 * 2 + 64 * 576), s);
   hipLaunchKernelGGL(conv3_p64_kernel, dim3(cus), dim3(512), kLds, s, a);

@@ -96,6 +96,22 @@ int make_chunk_major(const float* ws, int cout, int cin, float* dst,
   return 0;
 }
 
+__global__ void scale_vec_kernel(const float* __restrict__ a, float m, int n,
+                                 float* __restrict__ o) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] * m;
+}
+// copy of a folded per-channel vector in the split trunk's activation scale
+// (milan_ctx::act_scale, an exact power of two: the products are exact)
+static int scaled_copy(milan_ctx* c, const float* src, int n, float** dst, hipStream_t s) {
+  if (!src) { *dst = nullptr; return 0; }
+  MILAN_TRY(dev_alloc(c, (void**)dst, sizeof(float) * n));
+  hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src,
+                     c->act_scale, n, *dst);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static int pack_conv(milan_ctx* c, const std::string& conv,
                      const std::string& bn, int stride, int pad, ConvW* out,
                      hipStream_t s, bool split_without_bn = false) {
@@ -146,6 +162,7 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
   if ((g || split_without_bn) && out->cin % 32 == 0) {  // split-f16 copy
     MILAN_TRY(make_split_weight(c, out->w, out->cout, out->Kp, &out->ws,
                                 &out->ws_inv, s));
+    if (out->ws) MILAN_TRY(scaled_copy(c, out->bias, out->cout, &out->bias_s, s));
 #if MILAN_EXPERIMENTS
     if (out->ws && out->kh == 3 && out->kw == 3 && out->Kp == out->K &&
         out->cin % 16 == 0) {
@@ -197,6 +214,7 @@ static int fuse_c3_down(milan_ctx* c, Bottleneck* b, hipStream_t s) {
                      c3.bias, dn.bias, f.cout, f.bias);
   MILAN_CHECK_HIP(hipGetLastError());
   MILAN_TRY(make_split_weight(c, f.w, f.cout, f.Kp, &f.ws, &f.ws_inv, s));
+  MILAN_TRY(scaled_copy(c, f.bias, f.cout, &f.bias_s, s));
   b->c3d = f;
   return 0;
 }
@@ -288,6 +306,8 @@ int encoder_finalize(milan_ctx* c, hipStream_t s) {
     hipLaunchKernelGGL(bn_affine_kernel, dim3((w + 255) / 256), dim3(256), 0, s,
                        tg->dev, tb->dev, tm->dev, tv->dev, w, c->bn1_scale,
                        c->bn1_shift);
+    MILAN_TRY(scaled_copy(c, c->bn1_scale, w, &c->bn1_scale_s, s));
+    MILAN_TRY(scaled_copy(c, c->bn1_shift, w, &c->bn1_shift_s, s));
   }
   const bool basic = kind == MILAN_TRUNK_BASIC;
   for (int li = 0; li < 4; ++li) {
@@ -428,7 +448,7 @@ __device__ inline void enc_split8(const float* v, f32x4_t* hi_out,
 
 // split-format groups [hi x8 | lo x8] -> 8 fp32 values each
 __global__ void split_to_f32_kernel(const float* __restrict__ x, long groups,
-                                    float* __restrict__ y) {
+                                    float* __restrict__ y, float mul) {
   for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < groups;
        q += (long)gridDim.x * blockDim.x) {
     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(x + q * 8);
@@ -438,8 +458,8 @@ __global__ void split_to_f32_kernel(const float* __restrict__ x, long groups,
     f32x4_t o0, o1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o0[e] = (float)hh[e] + (float)ll[e];
-      o1[e] = (float)hh[4 + e] + (float)ll[4 + e];
+      o0[e] = ((float)hh[e] + (float)ll[e]) * mul;
+      o1[e] = ((float)hh[4 + e] + (float)ll[4 + e]) * mul;
     }
     *reinterpret_cast<f32x4_t*>(y + q * 8) = o0;
     *reinterpret_cast<f32x4_t*>(y + q * 8 + 4) = o1;
@@ -651,7 +671,7 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
     const float* __restrict__ tap, int P, int C, int level, Levels lv,
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
     const int* __restrict__ list_n, float* __restrict__ features, int fstride,
-    int col_off, int img0) {
+    int col_off, int img0, float inv_scale) {
   __shared__ float part[4][64];
   // `tap` points at image img0 of the batch; lists / features are indexed by
   // the absolute image number
@@ -686,9 +706,10 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
   part[phase][threadIdx.x & 63] = acc0 + acc1;
   __syncthreads();
   if (phase == 0 && c < C) {
+    // (inv_scale: 1 / activation scale of a split-format tap, an exact power of two)
     features[(long)img * fstride + col_off + c] =
-        (part[0][threadIdx.x] + part[1][threadIdx.x]) +
-        (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        ((part[0][threadIdx.x] + part[1][threadIdx.x]) +
+         (part[2][threadIdx.x] + part[3][threadIdx.x])) * inv_scale;
   }
 }
 
@@ -784,7 +805,7 @@ size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W) {
 static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
                           float* out, int epi, const float* aux,
                           const float* zero, int* Ho, int* Wo,
-                          bool split = false) {
+                          bool split = false, bool scaled_bias = true) {
   GemmArgs g{};
   *Ho = conv_out(H, cw.kh, cw.stride, cw.pad);
   *Wo = conv_out(W, cw.kw, cw.stride, cw.pad);
@@ -801,6 +822,8 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
     g.W = cw.ws; g.a_split = 1; g.out_split = 1; g.aux_split = aux != nullptr;
     g.acc_scale = cw.ws_inv;
     g.W3 = cw.ws3;
+    // the ResNet trunks keep split activations in the context's activation scale
+    if (scaled_bias && cw.bias_s) g.bias = cw.bias_s;
   }
   return g;
 }
@@ -945,11 +968,12 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (split && level > 0)
       hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off, img0);
+                         pl.list_w, pl.list_n, features, F, col_off, img0,
+                         1.f / c->act_scale);
     else
       hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off, img0);
+                         pl.list_w, pl.list_n, features, F, col_off, img0, 1.f);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   };
@@ -977,7 +1001,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       StemArgs sa{};
       sa.in = pl.in4; sa.ws = c->stem_pair.ws; sa.bias = c->stem_pair.bias;
       sa.acc_scale = c->stem_pair.ws_inv;
-      sa.scale = c->bn1_scale; sa.shift = c->bn1_shift;
+      sa.scale = c->bn1_scale_s; sa.shift = c->bn1_shift_s;  // (activation scale)
       sa.raw = spatial ? nullptr : pl.raw; sa.y = pl.x0;
       sa.bbox = spatial ? nullptr : pl.bbox;
       sa.zero = c->zero;
@@ -1000,7 +1024,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (split)
       hipLaunchKernelGGL(bn_relu_maxpool_split_kernel, dim3(blocks), dim3(256), 0,
                          s, pl.raw, n, pl.h1, pl.w1, wd, pl.hp, pl.wp,
-                         c->bn1_scale, c->bn1_shift, pl.x0);
+                         c->bn1_scale_s, c->bn1_shift_s, pl.x0);
     else
       hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, s,
                          (const float4*)pl.raw, n, pl.h1, pl.w1, wd / 4, pl.hp,
@@ -1068,7 +1092,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                               b.c2.pad)) {
         // layer1's 3x3: weights in registers, input tile staged once (conv3.hip)
         Conv3Args ca{};
-        ca.in = pl.t1; ca.ws = b.c2.ws; ca.bias = b.c2.bias; ca.acc_scale = b.c2.ws_inv;
+        ca.in = pl.t1; ca.ws = b.c2.ws; ca.bias = b.c2.bias_s; ca.acc_scale = b.c2.ws_inv;
         ca.out = pl.t2; ca.zero = c->zero; ca.n = n; ca.h = h1; ca.w = w1;
         MILAN_TRY(launch_conv3_p64(ca, s));
       } else {
@@ -1100,13 +1124,13 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                              w2 == w && chain_supported(P, b.down.cin, NR);
         if (plain || with_ds) {
           ChainArgs ca{};
-          ca.T2 = pl.t2; ca.X = y; ca.W1 = nb.c1.ws; ca.bias1 = nb.c1.bias;
+          ca.T2 = pl.t2; ca.X = y; ca.W1 = nb.c1.ws; ca.bias1 = nb.c1.bias_s;
           ca.T1 = pl.t1; ca.M = n * h2 * w2; ca.P = P; ca.scale1 = nb.c1.ws_inv;
           ca.NR = NR;
           if (plain) {
-            ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias; ca.R = x; ca.scale3 = b.c3.ws_inv;
+            ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias_s; ca.R = x; ca.scale3 = b.c3.ws_inv;
           } else {
-            ca.W3 = b.c3d.ws; ca.bias3 = b.c3d.bias; ca.A2 = x; ca.KD = b.down.cin;
+            ca.W3 = b.c3d.ws; ca.bias3 = b.c3d.bias_s; ca.A2 = x; ca.KD = b.down.cin;
             ca.scale3 = b.c3d.ws_inv;
           }
           MILAN_TRY(launch_chain(ca, s));
@@ -1162,7 +1186,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       const long total = rows * (C / 8);
       const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
       hipLaunchKernelGGL(split_to_f32_kernel, dim3(blocks), dim3(256), 0, s, x,
-                         total, spatial_out);
+                         total, spatial_out, 1.f / c->act_scale);
       MILAN_CHECK_HIP(hipGetLastError());
     } else {
       MILAN_CHECK_HIP(hipMemcpyAsync(spatial_out, x, sizeof(float) * rows * C,
@@ -1342,11 +1366,11 @@ static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (tap_split)
       hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
                          dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col, 0);
+                         pl.list_w, pl.list_n, features, F, col, 0, 1.f);
     else
       hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(n, (C + 63) / 64),
                          dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col, 0);
+                         pl.list_w, pl.list_n, features, F, col, 0, 1.f);
     MILAN_CHECK_HIP(hipGetLastError());
     col += C;
     return 0;
@@ -1380,8 +1404,9 @@ static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
   const float* in = pl.q[0];
   int h = pl.hq[0], w = pl.wq[0];
   for (int l = 1; l < 5; ++l) {
+    // (the AlexNet path keeps activation scale 1: its taps are pooled as stored)
     GemmArgs g = conv_args(c->alex[l], in, n, h, w, pl.a[l], EPI_BIAS_RELU,
-                           nullptr, c->zero, &ho, &wo, split);
+                           nullptr, c->zero, &ho, &wo, split, false);
     MILAN_REQUIRE(ho == pl.lv.h[l] && wo == pl.lv.w[l], MILAN_ERR_SHAPE,
                   "internal: alexnet level %d geometry mismatch", l);
     MILAN_TRY(launch_gemm(g, s));

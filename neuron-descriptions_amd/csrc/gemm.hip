@@ -40,6 +40,10 @@
 //   sees 16-byte per-lane accesses covering whole 256-B row segments.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -66,6 +70,37 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
+
+// ---- per-device launch state (a process may drive several GPUs: ADVICE r3) ------------
+// Opt a kernel in to `bytes` of dynamic LDS on the CURRENT device, once per (kernel, device).
+int ensure_lds_attr(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;
+  int dev = 0;
+  MILAN_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = done[{kern, dev}];
+  if (have < bytes) {
+    MILAN_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+  }
+  return 0;
+}
+// CUs of the current device, rounded down to whole XCD octets (persistent grids)
+int device_cus8(int* out) {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  MILAN_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int& n = cus[dev];
+  if (!n) {
+    MILAN_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    n = n < 8 ? 8 : n / 8 * 8;
+  }
+  *out = n;
+  return 0;
+}
 
 struct RowInfo {
   const float* base;
@@ -2174,13 +2209,7 @@ static int launch_conv3x3(const GemmArgs& g, hipStream_t s) {
   const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   auto kern = conv3x3_split16_kernel<BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kern),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, g, tiles_m,
                      tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
@@ -2240,13 +2269,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   auto kern = igemm_kernel<BM, BN, STAGES, CIN32, SPLIT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kern),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, g,
                      tiles_m, tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
@@ -2389,13 +2412,7 @@ static int launch_split16_impl(const GemmArgs& g, hipStream_t s) {
   const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   auto kern = igemm_split16_kernel<BM, BN, STAGES, SHAPE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kern),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   int grid = tiles_m * tiles_n;
 #if MILAN_EXPERIMENTS
   // MILAN_PERSIST=<workgroups>: persistent grid (a multiple of 8)
@@ -2418,13 +2435,7 @@ static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
   const size_t stage_bytes = size_t(NT / 64) * 32 * 68 * sizeof(float);
   if (lds < stage_bytes) lds = stage_bytes;
   auto kern = igemm_split16_tm2_kernel<BM, BN, STAGES>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kern),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, g, tiles_m,
                      tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
@@ -2437,22 +2448,11 @@ static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
   const size_t lds = size_t(5) * 256 * 32 * sizeof(float);
   auto kern = igemm_split16_pp32_kernel;
-  int dev = 0;
-  MILAN_CHECK_HIP(hipGetDevice(&dev));
-  static std::vector<char> attr_set(64, 0);
-  if (dev < 64 && !attr_set[dev]) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set[dev] = 1;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   // more tiles than CUs: persistent workgroups (a multiple of 8, so a workgroup's tiles stay
   // on its XCD), the next tile's first pairs prefetched under the epilogue
-  static std::vector<int> cus(64, 0);
-  if (dev < 64 && !cus[dev]) {
-    int n = 0;
-    MILAN_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    cus[dev] = n < 8 ? 8 : n / 8 * 8;
-  }
+  int ncus = 0;
+  MILAN_TRY(device_cus8(&ncus));
   int grid = tiles_m * tiles_n;
   // MILAN_PP_PERSIST=1: persistent workgroups with the next tile's first pairs prefetched
   // under the epilogue.  Measured (same-box A/B, profiles/r4_experiments.txt B): 1166 -> 1160
@@ -2460,7 +2460,7 @@ static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
   // 12-piece prologue it hides; one tile per workgroup (hardware dispatch) is the default.
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("MILAN_PP_PERSIST"); persist = e ? atoi(e) : 0; }
-  if (persist && dev < 64 && grid > cus[dev]) grid = cus[dev];
+  if (persist && grid > ncus) grid = ncus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g, tiles_m, tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
@@ -2472,14 +2472,7 @@ static int launch_split16_pp(const GemmArgs& g, hipStream_t s) {
   static_assert(size_t(4) * 512 * 16 * sizeof(float) >= size_t(8) * 32 * 68 * sizeof(float),
                 "the epilogue stages through the ring");
   auto kern = igemm_split16_pp_kernel;
-  int dev = 0;
-  MILAN_CHECK_HIP(hipGetDevice(&dev));
-  static std::vector<char> attr_set(64, 0);  // per device
-  if (dev < 64 && !attr_set[dev]) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set[dev] = 1;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, g, tiles_m, tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
@@ -2527,13 +2520,8 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
     if constexpr (BM == 256 && BN == 256 && STAGES == 5) {
       // more tiles than CUs: persistent workgroups, the next tile's A rows prefetched
       // under the epilogue (igemm_split16_linp_kernel)
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        MILAN_CHECK_HIP(hipGetDevice(&dev));
-        MILAN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus < 8 ? 8 : cus / 8 * 8;
-      }
+      int cus = 0;
+      MILAN_TRY(device_cus8(&cus));
       bool on = true;
 #if MILAN_EXPERIMENTS
       static int plin = -1;

@@ -323,13 +323,7 @@ static int launch_stem_cfg(StemArgs a, int cus, hipStream_t s) {
   a.tiles_y = (a.hp + PR - 1) / PR;
   a.tiles_x = (a.wp + PC - 1) / PC;
   auto kern = stem_fused_kernel<PR, PC, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)T::kLds));
-    attr_set = true;
-  }
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)T::kLds));
   // persistent: one workgroup per CU (8 waves) or two (4 waves each)
   hipLaunchKernelGGL(kern, dim3(cus * (NW == 8 ? 1 : 2)), dim3(NW * 64), T::kLds, s, a);
   MILAN_CHECK_HIP(hipGetLastError());
@@ -340,13 +334,8 @@ int launch_stem_fused(const StemArgs& a, hipStream_t s) {
   MILAN_REQUIRE(a.n > 0 && a.H > 0 && a.G > 0 && a.in && a.ws && a.y && a.scale &&
                     a.shift && a.zero,
                 MILAN_ERR_ARG, "stem: missing operand");
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    MILAN_CHECK_HIP(hipGetDevice(&dev));
-    MILAN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    cus = cus < 8 ? 8 : cus / 8 * 8;
-  }
+  int cus = 0;
+  MILAN_TRY(device_cus8(&cus));
   // algorithmic work: 7x7x3 taps per conv1 output; bytes: input groups once, raw
   // fp32 out, pooled split out
   const double px1 = (double)a.n * a.h1 * a.w1, pxp = (double)a.n * a.hp * a.wp;

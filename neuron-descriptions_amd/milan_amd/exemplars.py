@@ -82,14 +82,17 @@ def _checked_units(owner, units: Optional[torch.Tensor], channels: int):
     kernels index `units[u]` without a bounds check."""
     if units is None:
         return None
-    key = (units.data_ptr(), len(units), channels)
+    # the entry keeps `units` itself alive (its address cannot be handed to another
+    # tensor meanwhile) and `_version` notices in-place edits
+    key = (units.data_ptr(), len(units), channels, units._version)
     cache = owner.__dict__.setdefault('_units_checked', {})
     if key not in cache:
         host = units.detach().cpu().tolist()
         norm = _normalise_units(host, channels)
-        cache[key] = units if norm == host else torch.tensor(
-            norm, dtype=torch.int32, device=units.device)
-    return cache[key]
+        cache.clear()  # one live units tensor per owner is the use
+        cache[key] = (units, units if norm == host else torch.tensor(
+            norm, dtype=torch.int32, device=units.device))
+    return cache[key][1]
 
 
 def _as_hiddens(t: torch.Tensor) -> torch.Tensor:
@@ -156,13 +159,22 @@ class RunningTopK:
 
     # -- persistence: field names of netdissect's RunningTopK (runningstats.py:118-149)
     def state_dict(self) -> Dict[str, Any]:
+        """netdissect's layout (runningstats.py:118-134), loadable by its own class: a
+        candidate buffer of max(10, 5 k) columns per unit of which the first `next`
+        are filled, and `linear_index` = row offsets into the flattened buffer, shape
+        (units, 1) -- its `result()` adds them to a (units, k) index tensor."""
         values, index = self.result()
         units, filled = values.shape
+        width = max(10, 5 * self.k)
+        top_data = numpy.zeros((units, width), dtype=numpy.float32)
+        top_index = numpy.zeros((units, width), dtype=numpy.int64)
+        top_data[:, :filled] = values.cpu().numpy()
+        top_index[:, :filled] = index.cpu().numpy()
         return dict(constructor=f'{__name__}.RunningTopK()', k=self.k,
                     count=self.count, largest=True, data_shape=(units,),
-                    top_data=values.cpu().numpy(), top_index=index.cpu().numpy(),
-                    next=filled,
-                    linear_index=numpy.arange(units, dtype=numpy.int64) * filled,
+                    top_data=top_data, top_index=top_index, next=filled,
+                    linear_index=(numpy.arange(units, dtype=numpy.int64)
+                                  * width)[:, None],
                     perm=None)
 
     def set_state_dict(self, dic) -> None:
@@ -680,6 +692,10 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
     topk, rq = RunningTopK(k=k), RunningQuantile(r=4096)
     tally_args = dict(sample_size=None, k=k, r=4096)
     cached = _load_cache(tally_cache, tally_args)
+    if cached is not None and units is not None and (
+            'rtk.top_data' not in cached or
+            cached['rtk.top_data'].shape[0] != len(units)):
+        cached = None  # a tally of another unit list: recompute
     if cached is not None:
         topk.set_state_dict(_pull_prefix('rtk', cached))
         rq.set_state_dict(_pull_prefix('rq', cached))
@@ -726,9 +742,19 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
         for rank, imgnum in enumerate(ids_host[unit].tolist()):
             needed.setdefault(imgnum, []).append((unit, rank))
     order = sorted(needed)
+    # (upstream's gather_topk keys its cache on `count=topk.count`, tally.py; the digest
+    # of the top ids and of the unit list also notices another dataset / layer / units)
+    import hashlib
+    digest = hashlib.sha256(ids_host.numpy().tobytes() +
+                            repr(None if units is None else list(units)).encode()
+                            ).hexdigest()[:16]
     masks_args = dict(k=k, quantile=quantile, output_size=output_size,
-                      n_units=n_units)
+                      n_units=n_units, count=topk.count, top_ids=digest)
     rendered = _load_cache(masks_cache, masks_args)
+    if rendered is not None and any(
+            tuple(rendered[name].shape) != tuple(getattr(cells, name).shape)
+            for name in ('images', 'masks', 'masked')):
+        rendered = None
     if rendered is not None:
         for name in ('images', 'masks', 'masked'):
             getattr(cells, name).copy_(torch.from_numpy(rendered[name]))

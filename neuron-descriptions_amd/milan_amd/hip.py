@@ -238,6 +238,38 @@ def release_workspaces() -> None:
         torch.cuda.empty_cache()
 
 
+def other_compute_processes() -> list:
+    """PIDs of other processes that hold a compute (KFD) context on this machine's GPUs.
+    Each such process has a directory /sys/class/kfd/kfd/proc/<pid>."""
+    try:
+        pids = [int(p) for p in os.listdir('/sys/class/kfd/kfd/proc') if p.isdigit()]
+    except OSError:
+        return []
+    return sorted(p for p in pids if p != os.getpid())
+
+
+_SHARED_WARNED = False
+
+
+def warn_if_gpu_is_shared() -> None:
+    """The library's execution model is one process per GPU and one stream per process
+    (INTEGRATION.md): co-resident workgroups of different kernels are not safe on this
+    platform (profiles/r4_coresidency_minimal.txt -- a compiler-generated MFMA loop
+    corrupts the vector registers of a small kernel sharing its CU).  Ranks of one job
+    that were deliberately put on one GPU (tests) see this warning too."""
+    global _SHARED_WARNED
+    others = other_compute_processes()
+    if others and not _SHARED_WARNED:
+        _SHARED_WARNED = True
+        import warnings
+        warnings.warn(
+            f'milan_amd: {len(others)} other compute process(es) hold a GPU context '
+            f'(pids {others[:4]}{"..." if len(others) > 4 else ""}); if one of them '
+            'shares this device, kernels of the two processes can become co-resident '
+            'on a CU, which is unsupported (see INTEGRATION.md, "One process per GPU")',
+            RuntimeWarning, stacklevel=3)
+
+
 class Context:
     """Owns one `milan_ctx` (packed weights on one GPU) plus a workspace."""
 
@@ -245,6 +277,7 @@ class Context:
                  device: torch.device):
         self.lib = load_library()
         self.device = require_device(device)
+        warn_if_gpu_is_shared()
         self.dims = dims
         self._h = _P()
         with torch.cuda.device(self.device):

@@ -355,3 +355,29 @@ def test_two_rank_bench_weak_mode_all_legs(world):
     assert out['cpu_baseline'] is None and 'other_configs' not in out
     names = [st['stage'] for st in out['roofline']['stages']]
     assert 'encoder.layer3' in names and 'decoder.search' in names
+
+
+def test_bench_gpus_2_without_torchrun_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` started WITHOUT
+    torch.distributed.run must not die on WORLD_SIZE=1 -- the process becomes the
+    launcher of two ranks (sharding.self_launch; gloo ranks sharing the one GPU of this
+    box, RCCL one-rank-per-GPU on a node that has the GPUs) and rank 0 prints the one
+    JSON line.  This is the form a SCALE run without torchrun would take
+    (`python3 bench.py --gpus 8 --neurons-total 4096`)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR',
+                        'MASTER_PORT', 'MILAN_DIST_BACKEND')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, str(REPO / 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '0', '--chunk', '64', '--cpu-sample', '0',
+           '--also-f32-steps', '0', '--no-profile', '--from-host-steps', '0',
+           '--other-configs', '0', '--live-traffic', '0']
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(REPO),
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and len(line['per_rank']) == 2
+    assert line['steps'] == 2 and line['value'] > 0
+    assert line['scaling'] in ('weak', 'strong')

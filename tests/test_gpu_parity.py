@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from milan_amd import hip, synthetic
+from featclass import assert_feature_class
 from oracle import milan_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -119,7 +120,7 @@ def test_encoder_matches_reference_golden(dev, goldens, golden_meta, tag,
     else:
         got = ctx.encode(O.byte_to_float(images_u8[0]), masks_u8[0].float())
     want = goldens[f'g1_{tag}_features']
-    close(got, want, rtol=2e-3, atol=2e-4)
+    assert_feature_class(got, want)
     assert got[1].eq(0).all(), 'all-zero mask must give an exactly-zero row'
     assert not torch.isnan(got).any()
     ctx.close()
@@ -132,7 +133,7 @@ def test_encoder_no_mask_equals_all_ones(dev, golden_meta):
     got = ctx.encode(images_u8[0], None)
     ones = torch.ones(2, 1, 96, 96)
     want = O.encode(O.byte_to_float(images_u8), ones.unsqueeze(0), sd)[0]
-    close(got, want, rtol=2e-3, atol=2e-4)
+    assert_feature_class(got, want)
     ctx.close()
 
 
@@ -150,7 +151,7 @@ def test_encoder_large_and_oblong_images(dev, golden_meta, hw):
     want = O.encode(O.byte_to_float(images)[None], masks[None].float(), sd)[0]
     for precision in ('f32', 'split_f16'):
         ctx.set_precision(precision)
-        close(ctx.encode(images, masks), want, rtol=2e-3, atol=2e-4)
+        assert_feature_class(ctx.encode(images, masks), want, what=precision)
     ctx.close()
 
 
@@ -515,7 +516,7 @@ def test_split_f16_encoder_matches_reference_golden(dev, goldens, golden_meta,
                                        seed=m['image_seed'], zero_every=0)
     got = ctx.encode(images_u8[0], goldens[f'g1_{tag}_masks_u8'][0])
     want = goldens[f'g1_{tag}_features']
-    close(got, want, rtol=2e-3, atol=2e-4)
+    assert_feature_class(got, want, what='split_f16')
     assert got[1].eq(0).all()
     ctx.set_precision('f32')
     got32 = ctx.encode(images_u8[0], goldens[f'g1_{tag}_masks_u8'][0])
@@ -550,7 +551,7 @@ def test_split_f16_pixel_pair_stem(dev, hw):
     sp_u8 = ctx.encode(images, masks).cpu()
     sp_f = ctx.encode(O.byte_to_float(images), masks.float()).cpu()
     assert torch.equal(sp_u8, sp_f)
-    close(sp_u8, want, rtol=2e-3, atol=2e-4)
+    assert_feature_class(sp_u8, want, what='split_f16')
     tap0 = slice(0, width)
     scale = float(want[:, tap0].abs().max())
     assert float((sp_u8[:, tap0] - f32[:, tap0]).abs().max()) < 2e-6 * max(scale, 1.0)

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from milan_amd import encoders, hip, synthetic
+from featclass import assert_feature_class
 from oracle import milan_oracle as O
 from tests.test_trunk_goldens import TAGS, trunk_sd
 
@@ -39,7 +40,7 @@ def test_encoder_matches_reference_golden(dev, trunk_goldens, trunk_meta, tag,
     else:
         got = ctx.encode(O.byte_to_float(images_u8[0]), masks_u8[0].float())
     want = trunk_goldens[f'g11_{tag}_features']
-    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    assert_feature_class(got, want)
     assert got[1].eq(0).all(), 'all-zero mask must give an exactly-zero row'
     assert not torch.isnan(got).any()
     ctx.close()
@@ -69,8 +70,7 @@ def test_python_encoder_configs(dev, trunk_goldens, trunk_meta, config, tag):
                                        seed=m['image_seed'], zero_every=0)
     masks_u8 = trunk_goldens[f'g11_{tag}_masks_u8']
     got = enc(O.byte_to_float(images_u8[0]), masks_u8[0].float())
-    torch.testing.assert_close(got.cpu(), trunk_goldens[f'g11_{tag}_features'],
-                               rtol=2e-3, atol=2e-4)
+    assert_feature_class(got, trunk_goldens[f'g11_{tag}_features'])
     assert enc.properties()['config'] == config
     with pytest.raises(ValueError, match='encoder not supported'):
         encoders.PyramidConvEncoder('vgg16')
@@ -109,11 +109,11 @@ def test_spatial_encoder_matches_reference_golden(dev, trunk_goldens,
     want = trunk_goldens[f'g13_{tag}_features']
     got = ctx.encode_spatial(images_u8, masks_u8)
     assert got.shape == want.shape
-    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    assert_feature_class(got, want)
     got_f = ctx.encode_spatial(
         O.byte_to_float(images_u8),
         None if masks_u8 is None else masks_u8.float())
-    torch.testing.assert_close(got_f.cpu(), want, rtol=2e-3, atol=2e-4)
+    assert_feature_class(got_f, want)
     ctx.close()
 
 
@@ -130,8 +130,7 @@ def test_spatial_encoder_module(dev, trunk_goldens, trunk_meta):
     enc.to('cuda')
     images_u8, masks_u8 = spatial_inputs(m)
     got = enc(O.byte_to_float(images_u8), masks_u8.float())
-    torch.testing.assert_close(got.cpu(), trunk_goldens['g13_sp_96_features'],
-                               rtol=2e-3, atol=2e-4)
+    assert_feature_class(got, trunk_goldens['g13_sp_96_features'])
     with pytest.raises(ValueError, match='encoder not supported'):
         encoders.SpatialConvEncoder('resnet50')
     # the 224x224 geometry the reference hard-codes: (49, 512)
@@ -167,8 +166,7 @@ def test_decoder_over_spatial_encoder(dev):
     feats = O.encode_spatial(images, masks, trunk)
     want = O.forward(feats, sd, nv, 'greedy', length=6, mi=False)
     out = dec(images, masks, strategy='greedy')
-    torch.testing.assert_close(dec.encode(images, masks).cpu(), feats,
-                               rtol=2e-3, atol=2e-4)
+    assert_feature_class(dec.encode(images, masks), feats)
     top2 = want['predictions'].topk(2, dim=-1).values
     from tests.test_gpu_parity import assert_tokens_match
     assert_tokens_match(out.tokens, want['tokens'], top2[..., 0] - top2[..., 1])

@@ -10,11 +10,11 @@
 //                                            4 old kernel, ds_read one float at a time (volatile)
 #ifdef WITH_MILAN
 #include "../../neuron-descriptions_amd/csrc/common.h"
-#include <thread>
-#include <atomic>
 #else
 #include <hip/hip_runtime.h>
 #endif
+#include <thread>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,6 +78,41 @@ __global__ __launch_bounds__(256) void context_scalar(const float* __restrict__ 
     reinterpret_cast<float4*>(ctx + (long)r * F)[f] = s;
   }
 }
+// Library-independent aggressor: a bare v_mfma_f32_32x32x16_f16 loop at
+// the split16 GEMM's occupancy -- 512 threads = two waves per SIMD, ~230 VGPRs (fourteen
+// accumulator tiles), 128 KB of LDS claimed so that one workgroup owns a CU and the
+// victim's small workgroups fill the rest -- with NO LDS-DMA, no LDS traffic, no inline
+// asm: registers and the kernel descriptor are entirely the compiler's.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NACC>
+__global__ __launch_bounds__(512, 2) void mfma_aggressor(float* __restrict__ out, int iters) {
+  extern __shared__ float lds[];
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  f16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (_Float16)(0.001f * (float)((threadIdx.x + e) & 15));
+    b[e] = (_Float16)(0.002f * (float)((threadIdx.x * 3 + e) & 7));
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) lds[threadIdx.x] = s;  // (keeps the LDS claim and the sums alive)
+  out[(long)blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 __global__ void fill(float* p, long n, unsigned seed) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
@@ -104,14 +139,32 @@ int main(int argc, char** argv) {
       default: hipLaunchKernelGGL((context_lds<64, true>), grid, dim3(256), 0, 0, att, feat, rpn, k, F, ctx); break;
     }
   };
-#ifdef WITH_MILAN
-  // optional IN-PROCESS neighbour: a second host thread keeps a GEMM of libmilan_hip
-  // running on its own stream (argv[4]: 1 split16 256x256x4, 2 split16 256x128x3,
-  // 3 fp32 igemm 128x128x2)
+  // optional IN-PROCESS neighbour: a second host thread keeps a kernel running on its own
+  // stream.  argv[4]: 4 = the bare MFMA loop above (14 accumulator tiles, ~230 VGPRs),
+  // 5 = the same with 6 tiles (~110 VGPRs); with -DWITH_MILAN (needs the experiments
+  // build of the library, which exports its launchers) also 1 split16 256x256,
+  // 2 split16 256x128x3, 3 fp32 igemm 128x128x2 of libmilan_hip.
   const int neighbour = argc > 4 ? atoi(argv[4]) : 0;
   std::atomic<bool> stop{false};
   std::thread load;
-  if (neighbour) {
+  if (neighbour >= 4) {
+    load = std::thread([&] {
+      hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      float* o; CK(hipMalloc((void**)&o, (size_t)1024 * 512 * 4));
+      const size_t lds = 128 * 1024;
+      if (neighbour == 4) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_aggressor<14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      else CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_aggressor<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      while (!stop.load()) {
+        for (int i = 0; i < 8; ++i) {
+          if (neighbour == 4) hipLaunchKernelGGL(mfma_aggressor<14>, dim3(1024), dim3(512), lds, s2, o, 400);
+          else hipLaunchKernelGGL(mfma_aggressor<6>, dim3(1024), dim3(512), lds, s2, o, 900);
+        }
+        CK(hipStreamSynchronize(s2));
+      }
+    });
+  }
+#ifdef WITH_MILAN
+  else if (neighbour) {
     load = std::thread([&] {
       using namespace milan;
       hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
@@ -159,10 +212,8 @@ int main(int argc, char** argv) {
       printf("\n");
     }
   }
-#ifdef WITH_MILAN
   stop.store(true);
   if (load.joinable()) load.join();
-#endif
   printf("variant %d: %ld iterations, %ld with mismatches\n", variant, iters, bad_iters);
   return bad_iters ? 1 : 0;
 }
