@@ -214,6 +214,88 @@ def cpu_baseline(sd, nv, beam, length, temperature, sample, gpu_describe=None,
     }
 
 
+class ClockPowerSampler:
+    """sclk and board power of one GPU sampled from sysfs (pp_dpm_sclk's current level,
+    hwmon power1_average / power1_input) on a host thread during the timed region: the
+    part is power-limited (profiles/r3_clocks_power.txt), so box-to-box spread of `value`
+    is explainable from the record.  Reads two small files every 0.25 s; no rocm-smi
+    process is started inside the timed region."""
+
+    def __init__(self, device_index: int = 0):
+        import glob
+        self.samples = []
+        self._stop = None
+        self._thread = None
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
+        bus = None
+        try:
+            bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+        except Exception:  # noqa: BLE001 -- older torch: no pci_bus_id
+            bus = None
+        self.sclk_path = None
+        for c in cards:
+            dev = os.path.dirname(c)
+            if bus is None or ('%02x:' % bus) in os.path.basename(os.path.realpath(dev)):
+                self.sclk_path = c
+                break
+        if self.sclk_path is None and cards:
+            self.sclk_path = cards[min(device_index, len(cards) - 1)]
+        self.power_path = None
+        if self.sclk_path:
+            base = os.path.dirname(self.sclk_path)
+            for name in ('power1_average', 'power1_input'):
+                hits = glob.glob(os.path.join(base, 'hwmon', 'hwmon*', name))
+                if hits:
+                    self.power_path = hits[0]
+                    break
+
+    def _read(self):
+        mhz = watts = None
+        try:
+            for line in open(self.sclk_path).read().splitlines():
+                if line.rstrip().endswith('*'):
+                    mhz = float(line.split(':')[1].strip().split('M')[0])
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            if self.power_path:
+                watts = float(open(self.power_path).read()) / 1e6
+        except Exception:  # noqa: BLE001
+            pass
+        return mhz, watts
+
+    def start(self):
+        import threading
+        if not self.sclk_path:
+            return
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._read())
+                self._stop.wait(0.25)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        mhz = sorted(m for m, _ in self.samples if m)
+        watts = sorted(w for _, w in self.samples if w)
+        if not mhz and not watts:
+            return None
+
+        def stats(v):
+            return None if not v else {'mean': sum(v) / len(v), 'median': v[len(v) // 2],
+                                       'min': v[0], 'max': v[-1]}
+        return {'samples': len(self.samples), 'sclk_mhz': stats(mhz),
+                'board_power_w': stats(watts),
+                'source': 'sysfs pp_dpm_sclk (current level) + hwmon power1_average, '
+                          'every 0.25 s during the timed region, rank 0\'s GPU'}
+
+
 def measure_traffic_live(args):
     """HBM bytes per launch of the dominant GEMM kernel, measured NOW: two child runs of
     this script (one step, same chunk, same precision) under `rocprofv3 --kernel-trace
@@ -512,11 +594,15 @@ def main():
     torch.cuda.synchronize()
     if not args.no_profile:
         hip.profile_enable(True)
+    sampler = ClockPowerSampler(device.index or 0) if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     outs = [step(i, sizes[i]) for i in range(n_steps)]
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = time.perf_counter() - t0
+    clocks_power = sampler.stop() if sampler else None
     gemm_ms = gemm_flops = gemm_launches = stages = None
     if not args.no_profile:
         gemm_ms, gemm_flops, gemm_launches = hip.profile_read()
@@ -596,7 +682,10 @@ def main():
                 ('config1: 256 neurons (alexnet conv5 width), greedy, mi=False',
                  256, hip.GREEDY, 1),
                 ('config2: 1152 neurons (alexnet all units), beam 16 + rerank',
-                 1152, hip.RERANK, 16)):
+                 1152, hip.RERANK, 16),
+                # the metric's own size, exactly (the headline cycles 640-neuron chunks)
+                (f'config4 exact: 4096 neurons ({4096 // args.chunk} x {args.chunk} + '
+                 f'{4096 % args.chunk}), beam 50 + rerank', 4096, hip.RERANK, 50)):
             szs = [min(args.chunk, total - a)
                    for a in range(0, total, args.chunk)]
             step(0, szs[0], strat, bm)
@@ -669,6 +758,7 @@ def main():
                 all_tokens.cpu().numpy().tobytes()).hexdigest(),
         },
         'host_reconstruct_ms': reconstruct_ms,
+        'clocks_power': clocks_power,
         # per rank (its own clock around its own steps): a straggler GPU is visible
         'per_rank': {
             'neurons': [int(x) for x in rank_neurons],

@@ -61,32 +61,9 @@ __device__ __forceinline__ f32x4 asm_load16(const float* base, unsigned off) {
   return v;
 }
 
-// float(h.f16[sel]) + float(l.f16[sel]) in one instruction (both conversions are exact:
-// the bits of (float)h + (float)l)
-template <int SEL>
-__device__ __forceinline__ float mix_add(float hpair, float lpair) {
-  float r;
-  if constexpr (SEL == 0)
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hpair), "v"(lpair));
-  else
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hpair), "v"(lpair));
-  return r;
-}
-// x - float(h.f16[sel])
-template <int SEL>
-__device__ __forceinline__ float mix_sub(float x, float hpair) {
-  float r;
-  if constexpr (SEL == 0)
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
-  else
-    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
-  return r;
-}
-__device__ __forceinline__ float cvt_pk(float a, float b) {  // (f16(a), f16(b)), RNE
-  float r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+template <int SEL> __device__ __forceinline__ float mix_add(float h, float l) { return mix_add_f16<SEL>(h, l); }
+template <int SEL> __device__ __forceinline__ float mix_sub(float x, float h) { return mix_sub_f16<SEL>(x, h); }
+__device__ __forceinline__ float cvt_pk(float a, float b) { return cvt_pk_f16(a, b); }
 // 8 values already clamped to [0, 65504] -> (hi, lo) f16x8 pair: the roundings of
 // chain_split8 in 12 instructions instead of 32
 __device__ __forceinline__ void split8_fast(const float* x, f32x4* hi_out, f32x4* lo_out) {
@@ -105,28 +82,11 @@ __device__ __forceinline__ float clamp_relu(float u) {  // min(max(u, 0), 65504)
   return r;
 }
 
-// 8 fp32 -> (hi, lo) f16x8 pair, hi saturating (same roundings as gemm.hip's split8)
+// 8 fp32 <-> (hi, lo) f16x8 pair, hi saturating: common.h
 __device__ inline void chain_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
-  f32x4 hi, lo;
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    float x0, x1;
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(v[2 * d]), "v"(-65504.f), "v"(65504.f));
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(v[2 * d + 1]), "v"(-65504.f), "v"(65504.f));
-    hi[d] = cvt_pk(x0, x1);
-    lo[d] = cvt_pk(mix_sub<0>(x0, hi[d]), mix_sub<1>(x1, hi[d]));
-  }
-  *hi_out = hi;
-  *lo_out = lo;
+  split8_rne(v, hi_out, lo_out);
 }
-
-__device__ inline void chain_join8(f32x4 hi, f32x4 lo, float* v) {
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    v[2 * d] = mix_add<0>(hi[d], lo[d]);
-    v[2 * d + 1] = mix_add<1>(hi[d], lo[d]);
-  }
-}
+__device__ inline void chain_join8(f32x4 hi, f32x4 lo, float* v) { join8_exact(hi, lo, v); }
 
 constexpr int kSRow = 68;        // floats per row of a wave's LDS strip (64 + 4)
 constexpr int kTileFloats = 64 * 64;  // one weight tile: 64 rows x 64 k (16 KB)

@@ -285,6 +285,60 @@ struct Arena {
   }
 };
 
+// ---- split-f16 storage format, device side (one implementation for every kernel) -----
+// 8 fp32 -> (hi, lo) f16x8 pair; hi saturates instead of overflowing to inf:
+//   x = min(max(v, -65504), 65504);  hi = f16(x);  lo = f16(x - float(hi))
+// spelled with the instructions that do two of these steps at once -- v_med3_f32 (the
+// clamp), v_cvt_pk_f16_f32 (two roundings to f16, RNE), v_fma_mix_f32 (x - float(hi): the
+// f16 -> f32 conversion inside it is exact, so the one rounding is the subtraction's) --
+// 20 instructions per 8 values instead of 48, the same bits (tests/test_gpu_chain.py and
+// the token hash of the bench workload pin that).  V4 = any 4 x 32-bit vector type.
+__device__ __forceinline__ float cvt_pk_f16(float a, float b) {
+  float r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int SEL>   // x - float(f16 half SEL of hpair)
+__device__ __forceinline__ float mix_sub_f16(float x, float hpair) {
+  float r;
+  if constexpr (SEL == 0)
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  else
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x));
+  return r;
+}
+template <int SEL>   // float(f16 half SEL of hpair) + float(f16 half SEL of lpair)
+__device__ __forceinline__ float mix_add_f16(float hpair, float lpair) {
+  float r;
+  if constexpr (SEL == 0)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hpair), "v"(lpair));
+  else
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hpair), "v"(lpair));
+  return r;
+}
+template <typename V4>
+__device__ __forceinline__ void split8_rne(const float* v, V4* hi_out, V4* lo_out) {
+  V4 hi, lo;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float x0, x1;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(v[2 * d]), "v"(-65504.f), "v"(65504.f));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(v[2 * d + 1]), "v"(-65504.f), "v"(65504.f));
+    hi[d] = cvt_pk_f16(x0, x1);
+    lo[d] = cvt_pk_f16(mix_sub_f16<0>(x0, hi[d]), mix_sub_f16<1>(x1, hi[d]));
+  }
+  *hi_out = hi;
+  *lo_out = lo;
+}
+template <typename V4>   // (hi, lo) -> 8 fp32, v[e] = float(hi[e]) + float(lo[e])
+__device__ __forceinline__ void join8_exact(V4 hi, V4 lo, float* v) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    v[2 * d] = mix_add_f16<0>(hi[d], lo[d]);
+    v[2 * d + 1] = mix_add_f16<1>(hi[d], lo[d]);
+  }
+}
+
 }  // namespace milan
 
 struct milan_ctx {

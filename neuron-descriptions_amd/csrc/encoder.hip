@@ -432,18 +432,8 @@ __global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, int n,
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-__device__ inline void enc_split8(const float* v, f32x4_t* hi_out,
-                                  f32x4_t* lo_out) {
-  f16x8_t h, l;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    l[e] = (_Float16)(x - (float)hh);
-  }
-  *hi_out = __builtin_bit_cast(f32x4_t, h);
-  *lo_out = __builtin_bit_cast(f32x4_t, l);
+__device__ inline void enc_split8(const float* v, f32x4_t* hi_out, f32x4_t* lo_out) {
+  split8_rne(v, hi_out, lo_out);  // common.h
 }
 
 // split-format groups [hi x8 | lo x8] -> 8 fp32 values each

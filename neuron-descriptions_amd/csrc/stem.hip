@@ -75,16 +75,7 @@ struct StemTile {
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
 __device__ inline void stem_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
-  f16x8 h, l;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    l[e] = (_Float16)(x - (float)hh);
-  }
-  *hi_out = __builtin_bit_cast(f32x4, h);
-  *lo_out = __builtin_bit_cast(f32x4, l);
+  split8_rne(v, hi_out, lo_out);  // common.h
 }
 
 }  // namespace

@@ -238,14 +238,35 @@ def release_workspaces() -> None:
         torch.cuda.empty_cache()
 
 
+def _kfd_gpuids(pid) -> set:
+    """GPU ids (KFD topology ids) on which process `pid` has compute queues."""
+    ids = set()
+    try:
+        base = f'/sys/class/kfd/kfd/proc/{pid}/queues'
+        for q in os.listdir(base):
+            try:
+                with open(f'{base}/{q}/gpuid') as f:
+                    ids.add(f.read().strip())
+            except OSError:
+                pass
+    except OSError:
+        pass
+    return ids
+
+
 def other_compute_processes() -> list:
-    """PIDs of other processes that hold a compute (KFD) context on this machine's GPUs.
-    Each such process has a directory /sys/class/kfd/kfd/proc/<pid>."""
+    """PIDs of OTHER processes with compute queues on a GPU this process uses.  Every
+    process with a KFD context has a directory /sys/class/kfd/kfd/proc/<pid> whose
+    queues/*/gpuid name the devices it runs on; processes on other GPUs of the node (other
+    jobs' ranks, other containers) do not count."""
+    mine = _kfd_gpuids(os.getpid())
+    if not mine:
+        return []
     try:
         pids = [int(p) for p in os.listdir('/sys/class/kfd/kfd/proc') if p.isdigit()]
     except OSError:
         return []
-    return sorted(p for p in pids if p != os.getpid())
+    return sorted(p for p in pids if p != os.getpid() and _kfd_gpuids(p) & mine)
 
 
 _SHARED_WARNED = False
@@ -263,10 +284,10 @@ def warn_if_gpu_is_shared() -> None:
         _SHARED_WARNED = True
         import warnings
         warnings.warn(
-            f'milan_amd: {len(others)} other compute process(es) hold a GPU context '
-            f'(pids {others[:4]}{"..." if len(others) > 4 else ""}); if one of them '
-            'shares this device, kernels of the two processes can become co-resident '
-            'on a CU, which is unsupported (see INTEGRATION.md, "One process per GPU")',
+            f'milan_amd: {len(others)} other process(es) have compute queues on a GPU '
+            f'this process uses (pids {others[:4]}{"..." if len(others) > 4 else ""}): '
+            'kernels of two processes can become co-resident on a CU, which is '
+            'unsupported on this platform (see INTEGRATION.md, "One process per GPU")',
             RuntimeWarning, stacklevel=3)
 
 
@@ -277,7 +298,6 @@ class Context:
                  device: torch.device):
         self.lib = load_library()
         self.device = require_device(device)
-        warn_if_gpu_is_shared()
         self.dims = dims
         self._h = _P()
         with torch.cuda.device(self.device):
@@ -300,6 +320,7 @@ class Context:
             del keep
         self._ws: Optional[torch.Tensor] = None
         _LIVE_CONTEXTS.add(self)
+        warn_if_gpu_is_shared()  # (after the context exists: this process has queues)
         if os.environ.get('MILAN_CHAIN'):  # A/B timing (tools/ab_env.sh): flag bits
             bits = int(os.environ['MILAN_CHAIN'])
             self.set_fusion(chain=bool(bits & 1), wide=bool(bits & 2), stem=bool(bits & 4),

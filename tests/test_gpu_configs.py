@@ -368,6 +368,7 @@ def test_bench_gpus_2_without_torchrun_launches_its_own_ranks():
            if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR',
                         'MASTER_PORT', 'MILAN_DIST_BACKEND')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    hip.release_workspaces()  # the children share this GPU
     cmd = [sys.executable, str(REPO / 'bench.py'), '--gpus', '2', '--steps', '2',
            '--warmup', '0', '--chunk', '64', '--cpu-sample', '0',
            '--also-f32-steps', '0', '--no-profile', '--from-host-steps', '0',
@@ -378,6 +379,6 @@ def test_bench_gpus_2_without_torchrun_launches_its_own_ranks():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and len(line['per_rank']) == 2
+    assert line['n_gpus'] == 2 and len(line['per_rank']['neurons']) == 2
     assert line['steps'] == 2 and line['value'] > 0
     assert line['scaling'] in ('weak', 'strong')
