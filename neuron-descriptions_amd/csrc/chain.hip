@@ -560,9 +560,9 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = wave & 3, h = wave >> 2;
   const int px = lane & 31, half = lane >> 5;
-  float* ring = smem;                                   // [6][16 KB]
-  float* strip = smem + 6 * kTileFloats + p * 2048;     // 32 px x 64 channels
-  float* hand = smem + 6 * kTileFloats + 4 * 2048 + p * 2048;
+  float* strip = smem + p * 2048;                       // 32 px x 64 channels (8 KB per block)
+  float* hand = smem + 4 * 2048 + p * 2048;             // hand-over, 8 KB per block
+  float* ring = smem + 8 * 2048;                        // [6][16 KB]
 
   const long m0 = (long)blockIdx.x * 128 + p * 32;      // pixel block's first pixel
   const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
   auto issue_pair = [&](int q) {
     q = q < NIT ? q : NIT - 1;
     const int s = q >> 2, it = q & 3;
-    float* dst = ring + ((q % 3) * 2 + h) * kTileFloats + (wave & 3) * 256;
+    float* dst = ring + (h * 3 + q % 3) * kTileFloats + (wave & 3) * 256;  // h's three slots
     if (it < 2) {
       int sl = h == 0 ? s : s - 1;
       sl = sl < 0 ? 0 : (sl > NSLAB - 1 ? NSLAB - 1 : sl);
@@ -657,16 +657,53 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
   auto wfrag = [&](const float* slot, int sw, int t, int c) -> f32x4 {
     return *reinterpret_cast<const f32x4*>(slot + (32 * t + px) * 64 + ((c ^ sw) << 2));
   };
-  // weight fragments of k-step s4 of the wave's tile: [hi, lo] of MFMA tile 0, then of
-  // tile 1; double buffered (the reads of step s4 + 1 fly under step s4's MFMAs)
-  f32x4 wf[2][4];
-  auto load_w = [&](const float* slot, int s4, int buf) {
-    const int sw = opaque(fsw);
+  // Fragment reads with NO vector ALU in the MFMA phases (a VALU instruction next to the
+  // partner wave's MFMA stream costs 10-20 cycles: profiles/r4_mainloop_prototype.txt).
+  // fa[2 s4 + e]: LDS address, inside the block's strip, of this lane's (hi | lo = e) chunk
+  // of k-step s4; wa[] = the same inside the wave's weight tile of the current iteration
+  // (eight additions per iteration, before its MFMAs); the second MFMA tile (rows 32..63)
+  // is +8 KB, an immediate.  The reads are inline asm, so the waits are counted here, not
+  // by the compiler.
+  auto lds_addr = [](const float* p) { return (unsigned)(uintptr_t)(LDS_AS const float*)p; };
+  // (fa[] carries the strip's own address: the x' fragments are read at fa[], the weight
+  // fragments at wa[] = fa[] + (tile - strip), a scalar)
+  unsigned fa[8], wa[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      wf[buf][2 * t] = wfrag(slot, sw, t, 4 * s4 + 2 * half);
-      wf[buf][2 * t + 1] = wfrag(slot, sw, t, 4 * s4 + 2 * half + 1);
-    }
+  for (int k = 0; k < 8; ++k)
+    fa[k] = lds_addr(strip) +
+            (unsigned)((px * 64 + (((4 * (k >> 1) + 2 * half + (k & 1)) ^ fsw) << 2)) * 4);
+  const unsigned wbase = lds_addr(ring) + (unsigned)(h * 3) * (kTileFloats * 4) - lds_addr(strip);
+  f32x4 wf[2][4];   // [buffer][hi t0, lo t0, hi t1, lo t1]
+  f32x4 xf[2][2];   // [buffer][hi, lo]: x' fragment of the same k-step (reduce phase)
+  auto rd_x = [&](int buf, int s4) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][0]) : "v"(fa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][1]) : "v"(fa[2 * s4 + 1]) : "memory");
+  };
+  auto wait_wx = [&](int buf, bool last) {   // six reads per k-step in the reduce phase
+    if (last)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(6)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
+  };
+  auto rd_w = [&](int buf, int s4) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
+  };
+  // fragments of `buf` (and everything read before them) have landed; the four reads
+  // issued after them may still fly (LAST: nothing was issued after them)
+  auto wait_w = [&](int buf, bool last) {
+    if (last)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(4)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
   };
   // swizzled 32 x 64 strip: row r keeps its 16-byte chunk c at position c ^ (r & 15)
   auto to_strip = [&](float* st, const f32x16& a, int t) {
@@ -692,14 +729,28 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
   for (int s = 0; s <= NSLAB; ++s) {
     const bool expand_on = h == 0 ? s < NSLAB : s >= 1;
     f32x16 acc3[2];
+    // epilogue B's output rows, stored to HBM from inside the next iteration (defined on
+    // every path of the step, so that they are not carried around the loop)
+    f32x4 ehi[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 elo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int q = 4 * s + it;
-      // (the h = 0 waves issue their DMA pieces ahead of the MFMAs, the h = 1 waves behind
-      // them: eight waves issuing at once queue up at the CU's one LDS-DMA path)
-      if (h == 0) issue_pair(q + 2);
+      // VMEM of this iteration: the four DMA pieces of pair q + 2 and, in the iteration
+      // after an epilogue, that epilogue's HBM traffic -- the next residual / bias loads
+      // and the four x' stores (kept OUT of B: eighty 1 KB operations issued by eight
+      // waves at once queue for ~1300 cycles at the CU's one address unit).  The h = 0
+      // waves issue ahead of their MFMAs, the h = 1 waves in the middle of theirs.
+      auto vmem = [&]() { issue_pair(q + 2); };
+      if (h == 0) vmem();
       stamp(1);
-      const float* slot = ring + ((q % 3) * 2 + h) * kTileFloats;
+      {
+        int soff = (int)wbase + (q % 3) * (kTileFloats * 4);
+        asm volatile("" : "+s"(soff));   // (eight adds per iteration, not 24 registers)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wa[k] = fa[k] + (unsigned)soff;
+      }
+      bool issued = h == 0;
       if (it < 2) {
         // ---- A: this wave's half of the expand product --------------------------------
         if (it == 0) {
@@ -721,11 +772,12 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
           }
         }
         if (expand_on) {
-          load_w(slot, 0, 0);
+          rd_w(0, 0);
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
             const int ks = 4 * it + s4, b = s4 & 1;
-            if (s4 < 3) load_w(slot, s4 + 1, b ^ 1);
+            if (s4 < 3) rd_w(b ^ 1, s4 + 1);
+            wait_w(b, s4 == 3);
             acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
             acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
             acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
@@ -733,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
             acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
             acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (s4 == 1 && h == 1) { issue_pair(q + 2); __builtin_amdgcn_sched_barrier(0); }
+            if (s4 == 1 && h == 1) { vmem(); issued = true; __builtin_amdgcn_sched_barrier(0); }
           }
           stamp(2);
           if (it == 1) {
@@ -753,41 +805,32 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
               }
             }
           }
-        } else if (h == 1) {
-          issue_pair(q + 2);   // (step 0: nothing to finish yet; the pieces are still issued)
         }
       } else if (s >= 1) {
         // ---- C: reduce over slab s - 1, output rows 128 h + 64 (it - 2) .. ------------------
         const int u0 = 2 * (it - 2);
-        f32x4 xh[4], xl[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const float* fp = strip + px * 64;
-          const int sw = opaque(fsw);
-          xh[s4] = *reinterpret_cast<const f32x4*>(fp + (((4 * s4 + 2 * half) ^ sw) << 2));
-          xl[s4] = *reinterpret_cast<const f32x4*>(fp + (((4 * s4 + 2 * half + 1) ^ sw) << 2));
-        }
-        load_w(slot, 0, 0);
+        rd_x(0, 0);
+        rd_w(0, 0);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const int b = s4 & 1;
-          if (s4 < 3) load_w(slot, s4 + 1, b ^ 1);
-          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xh[s4]), acc1[u0], 0, 0, 0);
-          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xh[s4]), acc1[u0 + 1], 0, 0, 0);
-          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xl[s4]), acc1[u0], 0, 0, 0);
-          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xl[s4]), acc1[u0 + 1], 0, 0, 0);
-          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xh[s4]), acc1[u0], 0, 0, 0);
-          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xh[s4]), acc1[u0 + 1], 0, 0, 0);
+          if (s4 < 3) { rd_x(b ^ 1, s4 + 1); rd_w(b ^ 1, s4 + 1); }
+          wait_wx(b, s4 == 3);
+          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
+          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
+          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (s4 == 1 && h == 1) { issue_pair(q + 2); __builtin_amdgcn_sched_barrier(0); }
+          if (s4 == 1 && h == 1) { vmem(); issued = true; __builtin_amdgcn_sched_barrier(0); }
         }
-      } else if (h == 1) {
-        issue_pair(q + 2);   // (no reduce in step 0: the pieces are still issued)
       }
+      if (!issued) vmem();   // (an iteration without MFMAs for this wave: steps 0 and 16)
       stamp(it < 2 ? 3 : 4);
       // Pair q + 1 must have landed.  VMEM ops younger than its pieces: the four pieces
-      // of pair q + 2 -- and, at the first iteration after an epilogue, that epilogue's
-      // four stores and six loads (stores may retire early: they are not counted on).
+      // of pair q + 2 -- and, in the iteration after an epilogue, the six loads and four
+      // stores issued with them (stores may retire early: they are not counted on).
       if (tail) wait_vmcnt<0>();
       else if (it == 2 && s >= 1) wait_vmcnt<10>();
       else wait_vmcnt<4>();
@@ -795,15 +838,14 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
       __builtin_amdgcn_s_barrier();
       stamp(5);
       if (it == 1 && s >= 1) {
-        // ---- B: epilogue of slab s - 1, rows 16 h .. 16 h + 15 of the block ---------------
-        // (the residual / bias registers were loaded one step ago: older than everything
-        // the last counted wait let fly)
+        // ---- B: epilogue of slab s - 1, rows 16 h .. 16 h + 15 of the block: LDS and ALU
+        // only (the residual / bias registers were loaded one step ago: older than
+        // everything the last counted wait let fly)
         asm volatile("" : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1]),
                           "+v"(bias3v[0]), "+v"(bias3v[1]));
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
           const int row = 16 * h + 8 * ps + erow;
-          const long m = m0 + row;
           float* sp0 = row_chunk(strip, row, 2 * (lane & 7));
           float* sp1 = row_chunk(strip, row, 2 * (lane & 7) + 1);
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp0);
@@ -816,15 +858,15 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
             v[4 + 2 * d] = clamp_relu(v1[2 * d] + bias3v[1][2 * d] + mix_add<0>(res[ps][0][2 + d], res[ps][1][2 + d]));
             v[5 + 2 * d] = clamp_relu(v1[2 * d + 1] + bias3v[1][2 * d + 1] + mix_add<1>(res[ps][0][2 + d], res[ps][1][2 + d]));
           }
-          f32x4 hi, lo;
-          split8_fast(v, &hi, &lo);
+          split8_fast(v, &ehi[ps], &elo[ps]);
+          const long m = m0 + row;
           if (m < g.M) {
             float* xp = xbase + 64 * (s - 1) + (eoff[ps] >> 2);
-            *reinterpret_cast<f32x4*>(xp) = hi;
-            *reinterpret_cast<f32x4*>(xp + 4) = lo;
+            *reinterpret_cast<f32x4*>(xp) = ehi[ps];
+            *reinterpret_cast<f32x4*>(xp + 4) = elo[ps];
           }
-          *reinterpret_cast<f32x4*>(sp0) = hi;
-          *reinterpret_cast<f32x4*>(sp1) = lo;
+          *reinterpret_cast<f32x4*>(sp0) = ehi[ps];
+          *reinterpret_cast<f32x4*>(sp1) = elo[ps];
         }
         load_res(s);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
