@@ -2414,7 +2414,8 @@ static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
   // 12-piece prologue it hides; one tile per workgroup (hardware dispatch) is the default.
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("MILAN_PP_PERSIST"); persist = e ? atoi(e) : 0; }
-  if (persist && grid > ncus) grid = ncus;
+  // (=2: only the short-K launches, whose prologue is a larger share of a tile)
+  if (persist && (persist != 2 || g.K <= 512) && grid > ncus) grid = ncus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g, tiles_m, tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;

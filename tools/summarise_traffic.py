@@ -12,7 +12,7 @@ import re
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out'
-dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r3_hbm_traffic.json'
+dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r4_hbm_traffic.json'
 
 
 def read(counter):
