@@ -135,9 +135,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   constexpr int STAGES = RES_LDS ? 7 : 4, AHEAD = STAGES - 1;
   constexpr int INFL = AHEAD - 2;   // tiles still in flight behind a complete tile q + 2
   constexpr int PIECES = 16 / NW;   // 1 KB DMA pieces per wave per tile
-  // VMEM ops of one epilogue: 8 stores + 8 residual DMA pieces, or 8 stores + 8
-  // residual loads + 2 bias loads
-  constexpr int C_OPS = RES_LDS ? 16 : (RES ? 18 : 10);
+  // VMEM ops of one epilogue that the ring waits may count on being outstanding: its 8
+  // residual DMA pieces, or its 8 residual loads + 2 bias loads.  The 8 stores are issued
+  // ahead of them and are NOT counted: a wait that allowed for them would be
+  // too lax if a toolchain merged or split a store, or if stores retired out of order --
+  // allowing for fewer operations than are in flight only waits a little longer.
+  constexpr int C_OPS = RES_LDS ? 8 : (RES ? 10 : 2);
   static_assert(P % 64 == 0 && (NW == 4 || NW == 8), "chain: configuration");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
