@@ -1743,12 +1743,15 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(ah[i]), as_f16x8(bl[j]),
                                                            acc[i][j], 0, 0, 0);
+#if !MILAN_DROP_CROSS_TERM  // (sensitivity check of the parity suite: a build WITHOUT the
+                            // Al . Bh product must fail it -- profiles/r4_experiments.txt I)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(al[i]), as_f16x8(bh[j]),
                                                            acc[i][j], 0, 0, 0);
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
