@@ -835,8 +835,8 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
       // of pair q + 2 -- and, in the iteration after an epilogue, the six loads and four
       // stores issued with them (stores may retire early: they are not counted on).
       if (tail) wait_vmcnt<0>();
-      else if (it == 2 && s >= 1) wait_vmcnt<10>();
-      else wait_vmcnt<4>();
+      else if (it == 2 && s >= 1 && s < NSLAB) wait_vmcnt<10>();
+      else wait_vmcnt<4>();   // (after the last epilogue: its 4 uncounted stores + 4 pieces)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       stamp(5);
@@ -871,7 +871,9 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
           *reinterpret_cast<f32x4*>(sp0) = ehi[ps];
           *reinterpret_cast<f32x4*>(sp1) = elo[ps];
         }
-        load_res(s);
+        // (inline-asm loads: their destination registers must stay live until they land --
+        // after the last epilogue nothing would read them, so none are issued there)
+        if (s < NSLAB) load_res(s);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         stamp(6);
