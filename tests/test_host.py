@@ -543,3 +543,12 @@ def test_bench_and_script_entry_points_parse():
     assert out.returncode != 0
     assert 'no CPU fallback' in out.stderr or 'HIP' in out.stderr or \
         'cuda' in out.stderr.lower()
+
+
+def test_shared_gpu_probe_is_quiet_without_a_gpu(recwarn):
+    """hip.other_compute_processes(): PIDs with compute queues on a GPU this process
+    uses (/sys/class/kfd/kfd/proc/<pid>/queues/*/gpuid).  A process without queues --
+    every CPU test -- has no such neighbours, and the warning stays silent."""
+    assert hip.other_compute_processes() == []
+    hip.warn_if_gpu_is_shared()
+    assert not [w for w in recwarn.list if 'compute queues' in str(w.message)]
