@@ -1564,10 +1564,16 @@ struct PpLoader {
 // prologue -- are requested before the epilogue runs and land under it; the epilogue stages
 // through the two ring slots the prefetch does not use (A slot 2 + W slot 1: 64 KB).
 // LDS: [A0 32K][A1 32K][W0 32K][A2 32K][W1 32K].
+// BNW: columns of the output tile.  256: wave tiles 128 x 64 (2 x 4 waves).  128 (round 4, the
+// N = 128 layers of layer2 and the odd-width products): wave tiles 64 x 64 (4 x 2 waves), the
+// SAME loader -- W rows 128..255 of a slot carry out-of-range offsets, for which the DMA writes
+// zeros without a fetch -- so every counted wait is the 256-column kernel's.
+template <int BNW>
 __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int tid, bool prefetched,
                                                   bool has_next, int ntile_m, int ntile_n) {
   const GemmArgs g = reload_gemm_args();
-  constexpr int BM = 256, BN = 256, BKP = 32, TM = 4, TN = 2;
+  constexpr int BM = 256, BN = 256, BKP = 32, TM = BNW == 256 ? 4 : 2, TN = 2;
+  static_assert(BNW == 256 || BNW == 128, "ping-pong tile: 256 or 128 columns");
   constexpr int SLOTF = BM * BKP;  // floats per 32 KB slot
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1575,7 +1581,8 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
   auto w_slot = [&](int sl) { return smem + (sl == 0 ? 2 : 4) * SLOTF; };
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = BNW == 256 ? wave >> 2 : wave >> 1, wn = BNW == 256 ? wave & 3 : wave & 1;
+  const int group = wave >> 2;   // ping-pong group: the row half of the tile
   const int HoWo = g.Ho * g.Wo;
   const int np = g.Kp / BKP;  // k-tile pairs
   const int k1_pairs = g.A2 ? g.K1 / BKP : 0x7fffffff;
@@ -1603,7 +1610,7 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
     L.srd_a2 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.A2 ? g.A2 + (long)img0 * g.a2_img_stride : g.A), 0, 0x7fffffff,
         0x00020000);
-    L.srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W + (long)tn * BN * g.Kp), 0,
+    L.srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W + (long)tn * BNW * g.Kp), 0,
                                                 0x7fffffff, 0x00020000);
     // (rows of a tile are consecutive: the per-lane divisions run on rem0 + row < HoWo + 256,
     // exact in float arithmetic with one correction step -- a tenth of an integer division)
@@ -1632,7 +1639,7 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
                                          ((long)(ho * g.stride2) * g.W2d + wo * g.stride2) *
                                              g.a2_pix_stride + q * 4) * 4)
                            : OOB;
-      L.vb[it] = tn * BN + row < g.N ? (unsigned)(((long)row * g.Kp + q * 4) * 4) : OOB;
+      L.vb[it] = (row < BNW && tn * BNW + row < g.N) ? (unsigned)(((long)row * g.Kp + q * 4) * 4) : OOB;
     }
     L.ia = L.iw = L.is_kh = L.is_kw = L.is_cin0 = 0;
     L.cin_limit = g.Cin;
@@ -1704,8 +1711,8 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
       const int off = ((sl * 4 + fhalf * 2 + hl) ^ fsw) * 4;
-      a_p[sl][hl] = a_slot(0) + (wm * 128 + frow) * BKP + off;
-      a_q[sl][hl] = a_slot(2) + (wm * 128 + frow) * BKP + off;
+      a_p[sl][hl] = a_slot(0) + (wm * (TM * 32) + frow) * BKP + off;
+      a_q[sl][hl] = a_slot(2) + (wm * (TM * 32) + frow) * BKP + off;
       b_p[sl][hl] = w_slot(0) + (wn * 64 + frow) * BKP + off;
       b_q[sl][hl] = w_slot(1) + (wn * 64 + frow) * BKP + off;
     }
@@ -1790,7 +1797,7 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   phase_barrier();
   int left = np;
-  if (wm == 0) {
+  if (group == 0) {
     read_even(I0{}, I0{});
     phase_barrier();
     auto pair = [&](auto sa_tag, auto sw_tag) {
@@ -1865,12 +1872,13 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = acc[i][j] * ge.acc_scale;
   // staging: A slot 2 + W slot 1 (contiguous 64 KB; the prefetch goes to A0, A1, W0)
-  run_epilogue<TM, TN, true>(ge, acc, a_slot(2), wave, lane, tile_m * BM + wm * 128,
-                             tile_n * BN + wn * 64);
+  run_epilogue<TM, TN, true>(ge, acc, a_slot(2), wave, lane, tile_m * BM + wm * (TM * 32),
+                             tile_n * BNW + wn * 64);
 }
 
-__global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, int tiles_m,
-                                                                    int tiles_n) {
+template <int BNW>
+__global__ __launch_bounds__(512, 2) void igemm_split16_pp32n_kernel(GemmArgs g, int tiles_m,
+                                                                     int tiles_n) {
   const int T = tiles_m * tiles_n;
   int q = blockIdx.x;
   if (q >= T) return;
@@ -1887,7 +1895,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, 
     }
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    split16_pp32_tile(tile_m, tile_n, tid, prefetched, has_next, ntile_m, ntile_n);
+    split16_pp32_tile<BNW>(tile_m, tile_n, tid, prefetched, has_next, ntile_m, ntile_n);
     if (!has_next) break;
     // the prefetch has landed, the epilogue's stores are out and its staging reads are done
     // before the next tile's DMA reuses the slots
@@ -1896,6 +1904,19 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, 
     q += gridDim.x;
     prefetched = true;
   }
+}
+
+__global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, int tiles_m,
+                                                                    int tiles_n) {
+  // (the 256-column form keeps its round-4 name: profiles and tools key on it)
+  const int T = tiles_m * tiles_n;
+  const int q = blockIdx.x;
+  if (q >= T) return;
+  const int tile = xcd_tile(q, T);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  split16_pp32_tile<256>(tile_m, tile_n, tid, false, false, tile_m, tile_n);
 }
 
 __global__ __launch_bounds__(512, 2) void igemm_split16_pp_kernel(GemmArgs g, int tiles_m,
@@ -2401,25 +2422,30 @@ static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
 
 // the ping-pong form of the 256 x 256 tile (4-slot ring: 128 KB of LDS)
 // ... staged in k-tile pairs (whole 128-byte lines): A ring 3 x 32 KB + W ring 2 x 32 KB
+template <int BNW>
 static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
-  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + BNW - 1) / BNW;
   const size_t lds = size_t(5) * 256 * 32 * sizeof(float);
-  auto kern = igemm_split16_pp32_kernel;
-  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
-  // more tiles than CUs: persistent workgroups (a multiple of 8, so a workgroup's tiles stay
-  // on its XCD), the next tile's first pairs prefetched under the epilogue
   int ncus = 0;
   MILAN_TRY(device_cus8(&ncus));
   int grid = tiles_m * tiles_n;
   // MILAN_PP_PERSIST=1: persistent workgroups with the next tile's first pairs prefetched
-  // under the epilogue.  Measured (same-box A/B, profiles/r4_experiments.txt B): 1166 -> 1160
-  // neurons/s, layer3 112.0 -> 112.9 ms -- the static tile assignment costs more than the
-  // 12-piece prologue it hides; one tile per workgroup (hardware dispatch) is the default.
+  // under the epilogue (=2: only the K <= 512 launches).  Measured slower in every form --
+  // static walk, short-K only, dynamic tile queue (profiles/r4_experiments.txt B, H, K): one
+  // tile per workgroup (hardware dispatch) is the default.
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("MILAN_PP_PERSIST"); persist = e ? atoi(e) : 0; }
-  // (=2: only the short-K launches, whose prologue is a larger share of a tile)
-  if (persist && (persist != 2 || g.K <= 512) && grid > ncus) grid = ncus;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g, tiles_m, tiles_n);
+  const bool walk = persist && (persist != 2 || g.K <= 512) && grid > ncus;
+  if (BNW == 256 && !walk) {
+    auto kern = igemm_split16_pp32_kernel;
+    MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g, tiles_m, tiles_n);
+  } else {
+    auto kern = igemm_split16_pp32n_kernel<BNW>;
+    MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
+    if (walk) grid = ncus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g, tiles_m, tiles_n);
+  }
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -2451,6 +2477,14 @@ static bool pp_eligible(const GemmArgs& g) {
 
 template <int BM, int BN, int STAGES>
 static int launch_split16(const GemmArgs& g, hipStream_t s) {
+  if constexpr (BM == 256 && BN == 128 && STAGES == 3) {
+    // MILAN_PP128=0: the round-3 lockstep 256 x 128 kernel (same bits; A/B timing)
+    static int pp128 = -1;
+    if (pp128 < 0) { const char* e = getenv("MILAN_PP128"); pp128 = e ? atoi(e) : 1; }
+    if (pp128 && !g.chunk_major && pp_eligible(g) && g.Cin % 32 == 0 &&
+        (!g.A2 || g.K1 % 32 == 0) && ((long)g.H + g.pad) < 32768 && ((long)g.Wd + g.pad) < 32768)
+      return launch_split16_pp32<128>(g, s);
+  }
   if constexpr (BM == 256 && BN == 256 && STAGES == 5) {
     static int pp = -1;  // MILAN_PP=0: the round-3 lockstep kernels (same bits; A/B timing)
     if (pp < 0) { const char* e = getenv("MILAN_PP"); pp = e ? atoi(e) : 1; }
@@ -2458,7 +2492,7 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
       // pp == 2: the 16-slot form everywhere (A/B timing)
       if (pp != 2 && g.Cin % 32 == 0 && (!g.A2 || g.K1 % 32 == 0) &&
           ((long)g.H + g.pad) < 32768 && ((long)g.Wd + g.pad) < 32768)
-        return launch_split16_pp32(g, s);
+        return launch_split16_pp32<256>(g, s);
       return launch_split16_pp(g, s);
     }
   }
