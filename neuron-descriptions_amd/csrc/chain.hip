@@ -653,13 +653,11 @@ __global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
     for (int r = 0; r < 16; ++r) acc1[u][r] = 0.f;
 
   const int fsw = px & 15;
-  // The swizzled LDS addresses are loop-invariant, and there are ~40 of them: left to
-  // itself the compiler keeps them all in registers (and spills).  An opaque copy of the
-  // swizzle term at each use site makes it recompute them (one v_xad_u32 per access).
+  // The swizzled LDS addresses of the strip accesses outside the MFMA phases are
+  // loop-invariant, and there are dozens of them: left to itself the compiler keeps them
+  // all in registers (and spills).  An opaque copy of the swizzle term at each use site
+  // makes it recompute them (one v_xad_u32 per access).
   auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
-  auto wfrag = [&](const float* slot, int sw, int t, int c) -> f32x4 {
-    return *reinterpret_cast<const f32x4*>(slot + (32 * t + px) * 64 + ((c ^ sw) << 2));
-  };
   // Fragment reads with NO vector ALU in the MFMA phases (a VALU instruction next to the
   // partner wave's MFMA stream costs 10-20 cycles: profiles/r4_mainloop_prototype.txt).
   // fa[2 s4 + e]: LDS address, inside the block's strip, of this lane's (hi | lo = e) chunk
