@@ -224,7 +224,14 @@ int milan_graph_stats(const milan_ctx* ctx, long long* captures,
  *                             significant bits), A.B = Ah.Bh + Ah.Bl + Al.Bh on
  *                             the f16 matrix cores with fp32 accumulation:
  *                             fp32-GEMM-class error at 1/3 of the f16 MFMA rate.
- * Switchable at any time between calls (both weight packings are kept). */
+ * Switchable at any time between calls (both weight packings are kept).
+ *
+ * In split mode the ResNet trunks keep their activations multiplied by a power of two
+ * (2^5; environment MILAN_ACT_SCALE_LOG2=<0..10>, read by milan_create): the `lo` half of
+ * an operand then stays in the f16 normal range down to activations of ~0.004 (1e-3-scale
+ * networks stay in the fp32 error class), while `hi` saturates at 65504 / 2^k (2047).  The
+ * scale is invisible at this interface: features, spatial features and descriptions are
+ * returned unscaled, and 2^0 reproduces the unscaled storage bit for bit. */
 enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
 
 /* Cross-layer fusions of the trunk (split-f16 mode; results are bitwise those of
@@ -243,7 +250,8 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
  * Default: MILAN_FUSE_CHAIN | MILAN_FUSE_STEM | MILAN_FUSE_CONV3 (environment MILAN_CHAIN=<flags>
  * overrides at context creation). */
 enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
-       MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): one wave per SIMD */
+       MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): two waves per SIMD, at parity with the
+                                      two launches; off by default */
        MILAN_FUSE_STEM = 4,
        MILAN_FUSE_CONV3 = 8 };     /* layer1's 3x3 convs: weights in registers (csrc/conv3.hip) */
 int milan_set_fusion(milan_ctx* ctx, int flags);
