@@ -414,13 +414,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
           if constexpr (RES) {
             chain_join8(rh, rl, a);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + a[e], 0.f);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = v[e] + a[e];
           }
           f32x4 hi, lo;
-          chain_split8(v, &hi, &lo);
+          split8_relu_rne(v, &hi, &lo);   // (ReLU folded into the clamp)
           if (m < g.M) {
             float* xp = g.X + m * N3 + n;
             *reinterpret_cast<f32x4*>(xp) = hi;
@@ -501,11 +498,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = fmaxf(v0[e] + b0[e], 0.f);
-        v[4 + e] = fmaxf(v1[e] + b1[e], 0.f);
+        v[e] = v0[e] + b0[e];
+        v[4 + e] = v1[e] + b1[e];
       }
       f32x4 hi, lo;
-      chain_split8(v, &hi, &lo);
+      split8_relu_rne(v, &hi, &lo);   // (ReLU folded into the clamp)
       if (m < g.M) {
         float* tp = g.T1 + m * N1 + n;
         *reinterpret_cast<f32x4*>(tp) = hi;

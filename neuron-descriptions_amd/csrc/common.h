@@ -330,6 +330,22 @@ __device__ __forceinline__ void split8_rne(const float* v, V4* hi_out, V4* lo_ou
   *hi_out = hi;
   *lo_out = lo;
 }
+// relu(v) and the clamp in one v_med3_f32: med3(v, 0, 65504) == min(max(max(v, 0), -65504),
+// 65504) for every input (NaN -> 0, -0 -> +0 like v_max_f32)
+template <typename V4>
+__device__ __forceinline__ void split8_relu_rne(const float* v, V4* hi_out, V4* lo_out) {
+  V4 hi, lo;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float x0, x1;
+    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(x0) : "v"(v[2 * d]), "v"(65504.f));
+    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(x1) : "v"(v[2 * d + 1]), "v"(65504.f));
+    hi[d] = cvt_pk_f16(x0, x1);
+    lo[d] = cvt_pk_f16(mix_sub_f16<0>(x0, hi[d]), mix_sub_f16<1>(x1, hi[d]));
+  }
+  *hi_out = hi;
+  *lo_out = lo;
+}
 template <typename V4>   // (hi, lo) -> 8 fp32, v[e] = float(hi[e]) + float(lo[e])
 __device__ __forceinline__ void join8_exact(V4 hi, V4 lo, float* v) {
 #pragma unroll

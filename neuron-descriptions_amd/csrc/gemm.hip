@@ -279,12 +279,11 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a[e];
           }
-          if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
           f32x4 hi, lo;
-          split8(v, &hi, &lo);
+          if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU)
+            split8_relu_rne(v, &hi, &lo);   // (ReLU folded into the clamp)
+          else
+            split8(v, &hi, &lo);
           float* cp = g.C + (long)m * g.ldc + n;
           *reinterpret_cast<f32x4*>(cp) = hi;
           *reinterpret_cast<f32x4*>(cp + 4) = lo;
