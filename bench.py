@@ -235,7 +235,10 @@ class ClockPowerSampler:
         self.sclk_path = None
         for c in cards:
             dev = os.path.dirname(c)
-            if bus is None or ('%02x:' % bus) in os.path.basename(os.path.realpath(dev)):
+            # sysfs name = domain:bus:device.function; compare the BUS field exactly
+            # ('00:' also matches the domain prefix '0000:' of every card: ADVICE r4)
+            parts = os.path.basename(os.path.realpath(dev)).split(':')
+            if bus is None or (len(parts) >= 3 and parts[1].lower() == '%02x' % bus):
                 self.sclk_path = c
                 break
         if self.sclk_path is None and cards:
@@ -445,6 +448,13 @@ def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
     return out
 
 
+def rccl_version():
+    try:
+        return '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # torch built without it
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -584,9 +594,11 @@ def main():
 
     def step(i, size=None, strat=None, bm=None):
         im, mk = chunk_of(i, args.chunk if size is None else size)
+        # (check=False: no status read / stream synchronisation inside the timed
+        # region; the status word accumulates and is read once after it)
         return ctx.describe(im, mk, strategy if strat is None else strat,
                             args.length, beam if bm is None else bm, False,
-                            args.temperature, group_size=16)
+                            args.temperature, group_size=16, check=False)
 
     for i in range(args.warmup):
         step(i)
@@ -603,10 +615,13 @@ def main():
     sharding.barrier()
     elapsed = time.perf_counter() - t0
     clocks_power = sampler.stop() if sampler else None
-    gemm_ms = gemm_flops = gemm_launches = stages = None
+    # split-f16 fails loudly: bit 0 = a value hit the +-65504 clamp in ANY timed step
+    status_flags = ctx.status(clear=True)
+    gemm_ms = gemm_flops = gemm_launches = stages = kernels = None
     if not args.no_profile:
         gemm_ms, gemm_flops, gemm_launches = hip.profile_read()
         stages = hip.profile_read_stages()
+        kernels = hip.profile_read_kernels()
         hip.profile_enable(False)
     rank_seconds = sharding.all_ranks(elapsed, device)
     rank_neurons = sharding.all_ranks(float(my_neurons), device)
@@ -643,7 +658,7 @@ def main():
         for i, (im, mk) in enumerate(
                 ingest.ChunkPrefetcher(fetch, host_steps, device)):
             o = ctx.describe(im, mk, strategy, args.length, beam, False,
-                             args.temperature, group_size=16)
+                             args.temperature, group_size=16, check=False)
             tok_host[i].copy_(o['tokens'], non_blocking=True)
             sc_host[i].copy_(o['scores'], non_blocking=True)
         torch.cuda.synchronize()
@@ -758,6 +773,14 @@ def main():
                 all_tokens.cpu().numpy().tobytes()).hexdigest(),
         },
         'host_reconstruct_ms': reconstruct_ms,
+        # status word after the timed steps (milan_status): 0 = no split-f16 value was
+        # clamped, no non-finite input pixel
+        'status_flags': status_flags,
+        # which collective backend the ranks used (a SCALE record must be auditable)
+        'dist_backend': (torch.distributed.get_backend()
+                         if sharding.is_distributed() else 'none (single process)'),
+        'rccl_version': rccl_version(),
+        'ranks_per_gpu': shared,
         'clocks_power': clocks_power,
         # per rank (its own clock around its own steps): a straggler GPU is visible
         'per_rank': {
@@ -808,18 +831,44 @@ def main():
             stages['dec_lm']['gemm_flops'] = lm_gflop(beam, rerank) * 1e9 * \
                 my_neurons
         pool_bytes = pooled_bytes_per_image(masks[:args.chunk])
+        # the DOMINANT kernel priced on its own launches (milan_profile_read_kernels):
+        # algorithmic FLOPs of its launches / their summed HIP-event time
+        kname = {'pp32_256': 'igemm_split16_pp32_kernel', 'pp32_128':
+                 'igemm_split16_pp32n_kernel<128>', 'split_other':
+                 'igemm_split16_kernel / igemm_kernel<SPLIT> (other split tiles)',
+                 'f32': 'igemm_kernel (v_mfma_f32_32x32x2_f32)', 'chain': 'chain_kernel',
+                 'chain_wide': 'chain3_kernel (layer3 expand -> reduce)',
+                 'stem': 'stem_fused_kernel', 'conv3': 'conv3_p64_kernel',
+                 'other': 'other'}
+        dom = max(kernels, key=lambda k: kernels[k]['ms']) if kernels else None
+        dk = kernels[dom] if dom else None
+        dom_achieved = (dk['flops'] / (dk['ms'] * 1e-3) / 1e12) if dk and dk['ms'] > 0 \
+            else achieved
         result['roofline'] = {
             'bound': 'mfma',
-            'kernel': ('igemm_split16_kernel (+ chain / stem / conv3 kernels of the front) '
-                       '(v_mfma_f32_32x32x16_f16, 3 per product)' if split else
-                       'igemm_kernel (v_mfma_f32_32x32x2_f32)'),
-            'achieved': achieved,
+            'kernel': (kname.get(dom, dom) + (' (v_mfma_f32_32x32x16_f16, 3 per product)'
+                                              if split else '')) if dom else None,
+            # achieved / frac: the dominant kernel's own launches
+            'achieved': dom_achieved,
             'peak': peak,
             'unit': 'TFLOP/s',
-            'frac': achieved / peak,
+            'frac': dom_achieved / peak,
+            'kernel_launches': int(dk['launches']) if dk else None,
+            'kernel_avg_launch_ms': dk['ms'] / dk['launches'] if dk and dk['launches'] else None,
+            'kernel_time_frac_of_step': dk['ms'] * 1e-3 / elapsed if dk else None,
+            'kernel_algorithmic_GB_per_launch': dk['bytes'] / dk['launches'] / 1e9
+            if dk and dk['launches'] else None,
+            # every GEMM-class launch together (the round 1-4 definition of `frac`)
+            'achieved_all_gemm': achieved,
+            'frac_all_gemm': achieved / peak,
             # the matrix cores execute 3 f16 MFMA flops per algorithmic flop
-            'mfma_issue_frac': (3 * achieved / peak) if split else
-            achieved / peak,
+            'mfma_issue_frac': (3 * dom_achieved / peak) if split else
+            dom_achieved / peak,
+            'by_kernel': {k: {'ms_per_step': v['ms'] / n_steps,
+                              'launches_per_step': v['launches'] / n_steps,
+                              'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                              'algorithmic_GBs': v['bytes'] / (v['ms'] * 1e-3) / 1e9}
+                          for k, v in kernels.items() if v['ms'] > 0} if kernels else None,
             'traffic': traffic_bytes,
             'traffic_note': traffic_note,
             'launches': gemm_launches,
@@ -859,6 +908,16 @@ def main():
                 g_alg * 1e9 * n32_neurons / (ms32 * 1e-3) / 1e12 /
                 PEAK_F32_MFMA_TFLOPS,
         }
+    # flat copies of the figures a record parser should not have to dig for
+    if result.get('pcie_inclusive'):
+        result['pcie_inclusive_value'] = result['pcie_inclusive']['value']
+    if result.get('f32_mode'):
+        result['f32_mode_value'] = result['f32_mode']['value']
+        result['f32_mode_frac'] = result['f32_mode']['roofline_frac_of_f32_mfma_peak']
+    if result.get('roofline') and result['roofline'].get('stages'):
+        result['stage_ms_per_256'] = {
+            st['stage']: st['ms_per_256_neurons'] for st in result['roofline']['stages']}
+        result['roofline_frac_all_gemm'] = result['roofline']['frac_all_gemm']
     if other is not None:
         result['other_configs'] = other
     if world == 1 and args.cpu_sample > 0:

@@ -36,7 +36,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MILAN_ABI_VERSION 6
+#define MILAN_ABI_VERSION 7
 
 enum {
   MILAN_OK = 0,
@@ -258,6 +258,35 @@ int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);
 
+/* Split-f16 mode fails LOUDLY (round 5).  The reference computes in plain fp32
+ * (src/milan/encoders.py:295-320) and never saturates; the (hi, lo) f16 storage clamps
+ * |x * 2^act_scale_log2| at 65504.  Every kernel that writes split format keeps the running
+ * maximum of what it clamped and ORs MILAN_STATUS_SATURATED into the context's device status
+ * word when the clamp was hit; the input conversion ORs MILAN_STATUS_NONFINITE_INPUT when a
+ * float pixel was NaN / Inf (the features of such an image are NaN at every pyramid level,
+ * exactly as the reference's pooling of NaN x mask yields them).
+ *   milan_status            copies the word to *flags (host), optionally clearing it;
+ *                           synchronises `stream`.  The Python mirror reads it after every
+ *                           encode / describe and raises FloatingPointError on
+ *                           MILAN_STATUS_SATURATED (or reruns the call in MILAN_PRECISION_F32
+ *                           when Decoder.precision == 'auto').
+ *   milan_set_act_scale_log2 activation scale 2^k of the split trunk, k in [0, 10]
+ *                           (replaces the MILAN_ACT_SCALE_LOG2 default of 5): `hi` saturates
+ *                           at 65504 / 2^k, `lo` leaves the f16 normal range below
+ *                           2^-3 / 2^k.  Rewrites the pre-scaled bias vectors in place.
+ *   milan_encoder_absmax    calibration: runs the trunk in MILAN_PRECISION_F32 over a sample
+ *                           and returns the largest |activation| of every tensor the split
+ *                           trunk would store (*absmax, host); Decoder.calibrate picks the
+ *                           scale from it.  Synchronises `stream`. */
+enum { MILAN_STATUS_SATURATED = 1, MILAN_STATUS_NONFINITE_INPUT = 2 };
+int milan_status(milan_ctx* ctx, uint32_t* flags, int clear, milan_stream stream);
+int milan_set_act_scale_log2(milan_ctx* ctx, int log2_scale, milan_stream stream);
+int milan_get_act_scale_log2(const milan_ctx* ctx);
+int milan_encoder_absmax(milan_ctx* ctx, const void* images, int image_dtype,
+                         int n_images, int height, int width, float* absmax,
+                         void* workspace, size_t workspace_bytes,
+                         milan_stream stream);
+
 /* Measurement hook (bench.py's roofline leg): while enabled, every launch of
  * the implicit-GEMM MFMA kernel is bracketed by HIP events on its launch
  * stream.  milan_profile_read synchronises the device and returns the summed
@@ -293,6 +322,23 @@ enum milan_stage {
   MILAN_STAGE_COUNT = 12
 };
 int milan_profile_read_stages(double* table /* [MILAN_STAGE_COUNT][6] */);
+
+/* The same records by kernel family: `table` receives MILAN_KERNEL_COUNT rows of 4
+ * doubles -- summed launch time (ms), algorithmic FLOPs, launches, algorithmic HBM bytes --
+ * so that bench.py's `roofline` can price the DOMINANT kernel on its own launches. */
+enum milan_kernel_family {
+  MILAN_KERNEL_OTHER = 0,
+  MILAN_KERNEL_PP32_256 = 1,    /* igemm_split16_pp32_kernel (256 x 256 ping-pong tile)  */
+  MILAN_KERNEL_PP32_128 = 2,    /* igemm_split16_pp32n_kernel<128>                       */
+  MILAN_KERNEL_SPLIT_OTHER = 3, /* the other split-f16 implicit-GEMM tiles               */
+  MILAN_KERNEL_F32 = 4,         /* igemm_kernel, v_mfma_f32_32x32x2_f32                  */
+  MILAN_KERNEL_CHAIN = 5,       /* chain_kernel (layer1 / layer2 expand -> reduce)       */
+  MILAN_KERNEL_CHAIN_WIDE = 6,  /* layer3 expand -> reduce chain                         */
+  MILAN_KERNEL_STEM = 7,        /* stem_fused_kernel                                     */
+  MILAN_KERNEL_CONV3 = 8,       /* conv3_p64_kernel                                      */
+  MILAN_KERNEL_COUNT = 9
+};
+int milan_profile_read_kernels(double* table /* [MILAN_KERNEL_COUNT][4] */);
 
 /* ---- exemplar computation ---------------------------
  * The stage that WRITES the images.npy / masks.npy this path reads

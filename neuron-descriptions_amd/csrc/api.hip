@@ -129,11 +129,20 @@ int milan_create(milan_ctx** out, int device, const milan_dims* dims) {
     int k = atoi(e);
     k = k < 0 ? 0 : (k > 10 ? 10 : k);
     c->act_scale = ldexpf(1.f, k);
+    c->act_scale_log2 = k;
   }
   int r = dev_alloc(c, (void**)&c->zero, 256);
   if (r == 0) {
     hipError_t e = hipMemset(c->zero, 0, 256);
     if (e != hipSuccess) r = (int)e;
+  }
+  if (r == 0) {
+    // status word (+ the calibration maximum next to it)
+    r = dev_alloc(c, (void**)&c->status, 256);
+    if (r == 0) {
+      hipError_t e = hipMemset(c->status, 0, 256);
+      if (e != hipSuccess) r = (int)e;
+    }
   }
   if (r != 0) { milan_destroy(c); return r; }
   *out = c;
@@ -167,6 +176,7 @@ int milan_finalize_weights(milan_ctx* c, milan_stream stream) {
   MILAN_REQUIRE(!c->finalized, MILAN_ERR_STATE, "weights already finalized");
   hipStream_t s = (hipStream_t)stream;
   MILAN_CHECK_HIP(hipSetDevice(c->device));
+  set_status_word(nullptr);  // (weight packing is not a saturation event of a call)
   MILAN_TRY(encoder_finalize(c, s));
   MILAN_TRY(decoder_finalize(c, s));
   MILAN_REQUIRE(c->stem.w || c->lstm_ih.w || c->lm_out.w, MILAN_ERR_STATE,
@@ -290,6 +300,7 @@ int milan_encode(milan_ctx* c, const void* images, int image_dtype,
   MILAN_REQUIRE((image_dtype == MILAN_DTYPE_U8 || image_dtype == MILAN_DTYPE_F32) &&
                     (mask_dtype == MILAN_DTYPE_U8 || mask_dtype == MILAN_DTYPE_F32),
                 MILAN_ERR_ARG, "bad dtype");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   return encoder_run(c, images, image_dtype, masks, mask_dtype, n_images, height,
@@ -306,6 +317,7 @@ int milan_encode_spatial(milan_ctx* c, const void* images, int image_dtype,
   MILAN_REQUIRE((image_dtype == MILAN_DTYPE_U8 || image_dtype == MILAN_DTYPE_F32) &&
                     (mask_dtype == MILAN_DTYPE_U8 || mask_dtype == MILAN_DTYPE_F32),
                 MILAN_ERR_ARG, "bad dtype");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   return encoder_run_spatial(c, images, image_dtype, masks, mask_dtype, n_images,
@@ -316,6 +328,7 @@ int milan_init_state(milan_ctx* c, const float* features, int n, int k, float* h
                      float* cc, void* workspace, size_t workspace_bytes,
                      milan_stream stream) {
   MILAN_REQUIRE(c && features && h && cc, MILAN_ERR_ARG, "null argument");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   return decoder_init_state(c, features, n, k, h, cc, a, (hipStream_t)stream);
@@ -329,6 +342,7 @@ int milan_step(milan_ctx* c, const float* features, int rows, int k,
   MILAN_REQUIRE(c && features && tokens && h && cc && predictions && h_out && c_out,
                 MILAN_ERR_ARG, "milan_step: null argument");
   MILAN_REQUIRE(rows > 0, MILAN_ERR_SHAPE, "milan_step: empty batch");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   return decoder_step(c, features, rows, k, tokens, h, cc, h_lm, c_lm,
@@ -343,6 +357,7 @@ int milan_decode(milan_ctx* c, const float* features, int n, int k, int strategy
                  float* beam_scores, int32_t* out_len, void* workspace,
                  size_t workspace_bytes, milan_stream stream) {
   MILAN_REQUIRE(c && features, MILAN_ERR_ARG, "milan_decode: null argument");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   DecodeCall d{features, n, k, strategy, length, beam_size, mi, temperature,
@@ -374,6 +389,7 @@ int milan_lm_score(milan_ctx* c, const int64_t* seqs, int rows, int L,
                    const int32_t* seq_len, float* out, void* workspace,
                    size_t workspace_bytes, milan_stream stream) {
   MILAN_REQUIRE(c && seqs && out, MILAN_ERR_ARG, "milan_lm_score: null argument");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   return decoder_lm_score(c, seqs, rows, L, seq_len, out, a, (hipStream_t)stream);
@@ -384,6 +400,7 @@ int milan_lm_logprobs(milan_ctx* c, const int64_t* seqs, int rows, int L,
                       milan_stream stream) {
   MILAN_REQUIRE(c && seqs && out, MILAN_ERR_ARG,
                 "milan_lm_logprobs: null argument");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   return decoder_lm_logprobs(c, seqs, rows, L, out, a, (hipStream_t)stream);
@@ -492,6 +509,67 @@ int milan_profile_read_stages(double* table) {
   return profile_read_stages(table);
 }
 
+int milan_profile_read_kernels(double* table) {
+  MILAN_REQUIRE(table, MILAN_ERR_ARG, "milan_profile_read_kernels: null table");
+  return profile_read_kernels(table);
+}
+
+int milan_status(milan_ctx* c, uint32_t* flags, int clear, milan_stream stream) {
+  MILAN_REQUIRE(c && flags, MILAN_ERR_ARG, "milan_status: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned host = 0;
+  MILAN_CHECK_HIP(hipMemcpyAsync(&host, c->status, sizeof(host), hipMemcpyDeviceToHost, s));
+  if (clear) MILAN_CHECK_HIP(hipMemsetAsync(c->status, 0, sizeof(unsigned), s));
+  MILAN_CHECK_HIP(hipStreamSynchronize(s));
+  *flags = host;
+  return 0;
+}
+
+int milan_set_act_scale_log2(milan_ctx* c, int k, milan_stream stream) {
+  MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
+  MILAN_REQUIRE(k >= 0 && k <= 10, MILAN_ERR_ARG,
+                "activation scale 2^%d outside 2^0 .. 2^10", k);
+  MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
+  c->act_scale = ldexpf(1.f, k);
+  c->act_scale_log2 = k;
+  // captured decode graphs do not hold trunk launches; nothing else caches the scale
+  return encoder_rescale(c, (hipStream_t)stream);
+}
+
+int milan_get_act_scale_log2(const milan_ctx* c) { return c ? c->act_scale_log2 : -1; }
+
+int milan_encoder_absmax(milan_ctx* c, const void* images, int image_dtype, int n_images,
+                         int height, int width, float* absmax, void* workspace,
+                         size_t workspace_bytes, milan_stream stream) {
+  MILAN_REQUIRE(c && images && absmax, MILAN_ERR_ARG, "milan_encoder_absmax: null argument");
+  MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
+  MILAN_REQUIRE(c->d.trunk_kind == MILAN_TRUNK_BOTTLENECK || c->d.trunk_kind == MILAN_TRUNK_BASIC,
+                MILAN_ERR_ARG, "calibration covers the ResNet trunks (the others keep scale 1)");
+  hipStream_t s = (hipStream_t)stream;
+  Arena a;
+  MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
+  float* feats = a.get<float>((size_t)n_images * c->d.feature_size);
+  MILAN_REQUIRE(feats, MILAN_ERR_WORKSPACE, "absmax: workspace too small");
+  Arena enc;
+  enc.base = a.base + a.off; enc.size = a.size - a.off; enc.off = 0;
+  unsigned* word = c->status + 8;
+  MILAN_CHECK_HIP(hipMemsetAsync(word, 0, sizeof(unsigned), s));
+  const int saved = c->precision;
+  c->precision = MILAN_PRECISION_F32;
+  c->calib = word;
+  set_status_word(nullptr);
+  const int r = encoder_run(c, images, image_dtype, nullptr, MILAN_DTYPE_U8, n_images, height,
+                            width, feats, enc, s);
+  c->calib = nullptr;
+  c->precision = saved;
+  MILAN_TRY(r);
+  unsigned bits = 0;
+  MILAN_CHECK_HIP(hipMemcpyAsync(&bits, word, sizeof(bits), hipMemcpyDeviceToHost, s));
+  MILAN_CHECK_HIP(hipStreamSynchronize(s));
+  memcpy(absmax, &bits, sizeof(float));
+  return 0;
+}
+
 int milan_describe(milan_ctx* c, const void* images, int image_dtype,
                    const void* masks, int mask_dtype, int n, int k, int height,
                    int width, int strategy, int length, int beam_size, int mi,
@@ -503,6 +581,7 @@ int milan_describe(milan_ctx* c, const void* images, int image_dtype,
   MILAN_REQUIRE(c && images, MILAN_ERR_ARG, "milan_describe: null argument");
   MILAN_REQUIRE(c->finalized, MILAN_ERR_STATE, "weights not finalized");
   MILAN_REQUIRE(n > 0 && k > 0, MILAN_ERR_SHAPE, "milan_describe: empty batch");
+  set_status_word(c->status);
   Arena a;
   MILAN_TRY(make_arena(workspace, workspace_bytes, &a));
   const size_t fcount = (size_t)n * k * c->d.feature_size;

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 31, half = lane >> 5;
+  float sat = 0.f;  // (common.h: saturation of the split clamp is loud)
   float* ring = smem;                                         // [STAGES][16 KB]
   float* strip = smem + STAGES * kTileFloats + wave * (32 * kSRow);
   // residual slab of the wave's 32 pixels (32 rows x 64 channels, DMA target: read
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
             for (int e = 0; e < 8; ++e) v[e] = v[e] + a[e];
           }
           f32x4 hi, lo;
-          split8_relu_rne(v, &hi, &lo);   // (ReLU folded into the clamp)
+          split8_relu_rne(v, &hi, &lo, &sat);   // (ReLU folded into the clamp)
           if (m < g.M) {
             float* xp = g.X + m * N3 + n;
             *reinterpret_cast<f32x4*>(xp) = hi;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
         v[4 + e] = v1[e] + b1[e];
       }
       f32x4 hi, lo;
-      split8_relu_rne(v, &hi, &lo);   // (ReLU folded into the clamp)
+      split8_relu_rne(v, &hi, &lo, &sat);   // (ReLU folded into the clamp)
       if (m < g.M) {
         float* tp = g.T1 + m * N1 + n;
         *reinterpret_cast<f32x4*>(tp) = hi;
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
       }
     }
   }
+  report_saturation(g.status, sat);
   if constexpr (PROF) {
     stamp(6);
     if (tid == 0 && g.prof)
@@ -955,7 +957,9 @@ static int launch_chainw(const ChainArgs& a, hipStream_t s) {
   return 0;
 }
 
-int launch_chain(const ChainArgs& a, hipStream_t s) {
+int launch_chain(const ChainArgs& a0, hipStream_t s) {
+  ChainArgs a = a0;
+  if (a.status == nullptr) a.status = status_word();
   const int NR = a.NR ? a.NR : a.P;
   MILAN_REQUIRE(chain_supported(a.P, a.KD, NR) && a.M > 0, MILAN_ERR_SHAPE,
                 "chain: unsupported planes %d (+%d) -> %d", a.P, a.KD, NR);
@@ -968,6 +972,7 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
   void* rec = gemm_profile_begin(
       2.0 * M * (4 * P) * (K3 + R1),
       4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * R1 + 4 * P * (K3 + R1)), s);
+  profile_tag_kernel(a.P == 256 ? MILAN_KERNEL_CHAIN_WIDE : MILAN_KERNEL_CHAIN);
   int r;
   static const bool one_wave = getenv("MILAN_CHAIN_WIDE_ONEWAVE") != nullptr;
   if (a.P == 256 && a.prof && one_wave) r = launch_chain_cfg<256, 4, true, 0, false, true>(a, s);

@@ -107,11 +107,20 @@ struct GemmArgs {
                       // consecutive k-tiles and hit L2 -- and W is packed to match (ConvW::ws3)
   float* C2;          // EPI_LSTM: new cell state
   float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
+  unsigned* status;   // device status word (MILAN_STATUS_* bits) or nullptr; filled by the
+                      // launcher from the calling context (set_status_word)
 };
 
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2 };
 
 int launch_gemm(const GemmArgs& g, hipStream_t s);
+// Status word of the context whose entry point is running on this thread (api.hip sets it
+// on entry): every kernel that writes split format ORs MILAN_STATUS_SATURATED into it when
+// its clamp to +-65504 was hit (split8_* below).  nullptr = nobody is listening.
+void set_status_word(unsigned* word);
+unsigned* status_word();
+// kernel family of the GEMM-class launch being recorded (milan_profile_read_kernels)
+void profile_tag_kernel(int family);
 // rows x K fp32 (row stride ld_src) -> split format (row stride ld_dst), x scale
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
                         long rows, int K, float scale, hipStream_t s);
@@ -144,6 +153,7 @@ struct ChainArgs {
   float scale3, scale1;  // 1 / weight scale of W3, W1
   long long* prof;       // timing experiments: per-workgroup phase cycles (8 per WG)
   int NR;                // output channels of the reduce conv (0 = P; 2 P at a stage boundary)
+  unsigned* status;      // filled by the launcher (status_word())
 };
 bool chain_supported(int P, int KD, int NR = 0);
 int launch_chain(const ChainArgs& a, hipStream_t s);
@@ -163,6 +173,7 @@ struct StemArgs {
   int n, H, G, h1, w1, hp, wp;
   int tiles_y, tiles_x;  // filled by the launcher
   int debug;             // timing experiments: 1 no MFMA, 2 no store phase, 4 no DMA, 8 no staging
+  unsigned* status;      // filled by the launcher (status_word())
 };
 bool stem_fused_supported(int cout, int Kp);
 int launch_stem_fused(const StemArgs& a, hipStream_t s);
@@ -178,12 +189,14 @@ struct Conv3Args {
   int tiles_y, tiles_x;  // filled by the launcher
   int debug;             // timing experiments: 1 no MFMA, 2 no epilogue, 4 no DMA, 8 no hand-over
   long long* prof;       // experiments build: per-phase cycle sums of workgroup 0 (16 values)
+  unsigned* status;      // filled by the launcher (status_word())
 };
 bool conv3_p64_supported(int cin, int cout, int kh, int kw, int stride, int pad);
 int launch_conv3_p64(const Conv3Args& a, hipStream_t s);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, long long* launches);
 int profile_read_stages(double* table /* [MILAN_STAGE_COUNT][6] */);
+int profile_read_kernels(double* table /* [MILAN_KERNEL_COUNT][4] */);
 // RAII bracket of one stage region on a stream: labels the GEMM launches made
 // inside it and, while profiling is on, times the region with two HIP events.
 class StageScope {
@@ -316,33 +329,57 @@ __device__ __forceinline__ float mix_add_f16(float hpair, float lpair) {
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hpair), "v"(lpair));
   return r;
 }
+// Saturation is LOUD (round 5): every thread keeps the running maximum `sat` of the clamped
+// magnitudes it has split (four v_max3_f32 per 8 values, no compare, no scalar traffic);
+// `sat >= 65504` at the end of the kernel means a value hit the clamp (or was exactly the
+// largest f16) and the kernel ORs MILAN_STATUS_SATURATED into the context's status word
+// (report_saturation).  The host raises / falls back to f32 (milan_amd/hip.py).
+// NaN: v_med3_f32 returns min3 when an operand is NaN, so a NaN accumulator leaves as 0 (ReLU
+// form) or -65504 (plain form).  A NaN cannot ARISE inside the trunk without a saturation
+// first (|x| > 65504 / act_scale is flagged long before fp32 overflows to Inf - Inf), and a
+// non-finite INPUT pixel poisons its whole image in the reference (every pyramid level pools
+// NaN x mask) -- that is reproduced at image level: preprocess_* marks the image, the pooling
+// / spatial read-out write NaN for it (encoder.hip, MILAN_STATUS_NONFINITE_INPUT).
+__device__ __forceinline__ float max3_abs(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float sat_fold8(const float* x, float sat) {
+  return max3_abs(max3_abs(x[0], x[1], x[2]), max3_abs(x[3], x[4], x[5]), max3_abs(x[6], x[7], sat));
+}
+__device__ __forceinline__ void report_saturation(unsigned* status, float sat) {
+  if (status != nullptr && sat >= 65504.f) atomicOr(status, 1u /* MILAN_STATUS_SATURATED */);
+}
 template <typename V4>
-__device__ __forceinline__ void split8_rne(const float* v, V4* hi_out, V4* lo_out) {
+__device__ __forceinline__ void split8_rne(const float* v, V4* hi_out, V4* lo_out, float* sat = nullptr) {
   V4 hi, lo;
+  float x[8];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    float x0, x1;
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(v[2 * d]), "v"(-65504.f), "v"(65504.f));
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(v[2 * d + 1]), "v"(-65504.f), "v"(65504.f));
-    hi[d] = cvt_pk_f16(x0, x1);
-    lo[d] = cvt_pk_f16(mix_sub_f16<0>(x0, hi[d]), mix_sub_f16<1>(x1, hi[d]));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x[2 * d]) : "v"(v[2 * d]), "v"(-65504.f), "v"(65504.f));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x[2 * d + 1]) : "v"(v[2 * d + 1]), "v"(-65504.f), "v"(65504.f));
+    hi[d] = cvt_pk_f16(x[2 * d], x[2 * d + 1]);
+    lo[d] = cvt_pk_f16(mix_sub_f16<0>(x[2 * d], hi[d]), mix_sub_f16<1>(x[2 * d + 1], hi[d]));
   }
+  if (sat) *sat = sat_fold8(x, *sat);
   *hi_out = hi;
   *lo_out = lo;
 }
 // relu(v) and the clamp in one v_med3_f32: med3(v, 0, 65504) == min(max(max(v, 0), -65504),
-// 65504) for every input (NaN -> 0, -0 -> +0 like v_max_f32)
+// 65504) for every finite input (-0 -> +0 like v_max_f32; NaN -> 0, see above)
 template <typename V4>
-__device__ __forceinline__ void split8_relu_rne(const float* v, V4* hi_out, V4* lo_out) {
+__device__ __forceinline__ void split8_relu_rne(const float* v, V4* hi_out, V4* lo_out, float* sat = nullptr) {
   V4 hi, lo;
+  float x[8];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    float x0, x1;
-    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(x0) : "v"(v[2 * d]), "v"(65504.f));
-    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(x1) : "v"(v[2 * d + 1]), "v"(65504.f));
-    hi[d] = cvt_pk_f16(x0, x1);
-    lo[d] = cvt_pk_f16(mix_sub_f16<0>(x0, hi[d]), mix_sub_f16<1>(x1, hi[d]));
+    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(x[2 * d]) : "v"(v[2 * d]), "v"(65504.f));
+    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(x[2 * d + 1]) : "v"(v[2 * d + 1]), "v"(65504.f));
+    hi[d] = cvt_pk_f16(x[2 * d], x[2 * d + 1]);
+    lo[d] = cvt_pk_f16(mix_sub_f16<0>(x[2 * d], hi[d]), mix_sub_f16<1>(x[2 * d + 1], hi[d]));
   }
+  if (sat) *sat = sat_fold8(x, *sat);
   *hi_out = hi;
   *lo_out = lo;
 }
@@ -389,7 +426,12 @@ struct milan_ctx {
   // copies below / ConvW::bias_s), and the consumers that leave the split domain (the
   // mask-weighted pooling and the spatial read-out divide by it).
   float act_scale = 32.f;
+  int act_scale_log2 = 5;
   float *bn1_scale_s = nullptr, *bn1_shift_s = nullptr;
+  // device status word (MILAN_STATUS_* bits, milan_status): ORed by the split epilogues when
+  // a value hit the +-65504 clamp and by the input conversion when a pixel was not finite
+  unsigned* status = nullptr;
+  unsigned* calib = nullptr;   // != nullptr only inside milan_encoder_absmax
   std::vector<milan::Bottleneck> blocks[4];
   float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   // decoder
@@ -414,6 +456,7 @@ int make_split_weight(milan_ctx* c, const float* w, int n, int kp, float** ws,
 int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
                     float* wp, hipStream_t s);
 int encoder_finalize(milan_ctx* c, hipStream_t s);
+int encoder_rescale(milan_ctx* c, hipStream_t s);
 // split 3x3 weights [n][tap][Cin] -> chunk-major [n][Cin/16][tap][16]
 int make_chunk_major(const float* ws, int cout, int cin, float* dst,
                      hipStream_t s);

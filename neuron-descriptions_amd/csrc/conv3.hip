@@ -52,8 +52,8 @@ static_assert(kIR * kIC * 16 == 4 * 2 * kBatch * 64, "two batches of the four lo
 
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-__device__ inline void c3_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
-  split8_rne(v, hi_out, lo_out);  // common.h
+__device__ inline void c3_split8(const float* v, f32x4* hi_out, f32x4* lo_out, float* sat) {
+  split8_rne(v, hi_out, lo_out, sat);  // common.h
 }
 
 // 18 k-slabs of one 32-pixel block: slab sg = 18 KH + s covers k-groups 2 sg (+1 for
@@ -104,6 +104,7 @@ __device__ __forceinline__ void c3_mfma(const char* buf, int pbase, int pc, int 
 __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) char c3_smem[];
   char* hand = c3_smem + kRing * kInBytes;  // [pair 0..3][parity][kHandBytes]
+  float sat = 0.f;  // (common.h: saturation of the split clamp is loud)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
               v[4 + e] = fmaxf(v1[e] + bias8[4 + e], 0.f);
             }
             f32x4 hi, lo;
-            c3_split8(v, &hi, &lo);
+            c3_split8(v, &hi, &lo, &sat);
             float* d = a.out + (((long)img * a.h + oy) * a.w + ox) * 64 + nb * 32 + e_g * 8;
             *reinterpret_cast<f32x4*>(d) = hi;
             *reinterpret_cast<f32x4*>(d + 4) = lo;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
   if (a.prof && blockIdx.x == 0 && lane == 0 && pair == 0)
     for (int k = 0; k < 4; ++k) a.prof[kh2 * 4 + k] = pt[k];
 #endif
+  report_saturation(a.status, sat);
 }
 
 bool conv3_p64_supported(int cin, int cout, int kh, int kw, int stride, int pad) {
@@ -304,11 +306,13 @@ int launch_conv3_p64(const Conv3Args& a0, hipStream_t s) {
                 MILAN_ERR_ARG, "conv3: missing operand");
   a.tiles_y = (a.h + kTR - 1) / kTR;
   a.tiles_x = (a.w + kTC - 1) / kTC;
+  if (a.status == nullptr) a.status = status_word();
   int cus = 0;
   MILAN_TRY(device_cus8(&cus));
   MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(conv3_p64_kernel), (int)kLds));
   const double px = (double)a.n * a.h * a.w;
   void* rec = gemm_profile_begin(2.0 * px * 64 * 576, 4.0 * (px * 64 * 2 + 64 * 576), s);
+  profile_tag_kernel(MILAN_KERNEL_CONV3);
   hipLaunchKernelGGL(conv3_p64_kernel, dim3(cus), dim3(512), kLds, s, a);
   gemm_profile_end(rec, s);
   MILAN_CHECK_HIP(hipGetLastError());

@@ -1408,13 +1408,8 @@ static int launch_row_select(const float* logits, const float* lm_logits,
   const size_t lds = row_select_lds(V);
   MILAN_REQUIRE(lds <= 160 * 1024, MILAN_ERR_SHAPE,
                 "vocab_size %d too large for the row-select kernel", V);
-  static size_t attr = 0;
-  if (lds > 64 * 1024 && lds > attr) {
-    MILAN_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(row_select_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = lds;
-  }
+  if (lds > 64 * 1024)  // per (kernel, device): a process may drive several GPUs
+    MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(row_select_kernel), (int)lds));
   hipLaunchKernelGGL(row_select_kernel, dim3(rows), dim3(256), lds, s, logits,
                      lm_logits, lambda, V, k, last_tok, stop, cand_v, cand_i,
                      pred_out, pred_stride);

@@ -368,7 +368,8 @@ __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
                                   float s0, float s1, float s2,
                                   float4* __restrict__ out,
                                   const void* __restrict__ mul = nullptr,
-                                  int mul_u8 = 1) {
+                                  int mul_u8 = 1, int* __restrict__ poison = nullptr,
+                                  unsigned* __restrict__ status = nullptr) {
   // the byte->float product is rounded on its own, as in the reference: no
   // contraction into the mean subtraction
 #pragma clang fp contract(off)
@@ -389,8 +390,16 @@ __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
     const float k = mul == nullptr ? 1.f
                     : mul_u8     ? (float)((const uint8_t*)mul)[p]
                                  : ((const float*)mul)[p];
-    out[p] = make_float4(((v0 - m0) / s0) * k, ((v1 - m1) / s1) * k,
-                         ((v2 - m2) / s2) * k, 0.f);
+    const float o0 = ((v0 - m0) / s0) * k, o1 = ((v1 - m1) / s1) * k, o2 = ((v2 - m2) / s2) * k;
+    if constexpr (sizeof(T) != 1) {
+      // a pixel that is not finite poisons its image: the reference's pyramid pools
+      // NaN x mask over every level (pinned by tests/test_gpu_status.py against the oracle)
+      if (poison != nullptr && !(fabsf(o0) + fabsf(o1) + fabsf(o2) < INFINITY)) {
+        poison[n] = 1;
+        if (status) atomicOr(status, 2u /* MILAN_STATUS_NONFINITE_INPUT */);
+      }
+    }
+    out[p] = make_float4(o0, o1, o2, 0.f);
   }
 }
 
@@ -432,8 +441,9 @@ __global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, int n,
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-__device__ inline void enc_split8(const float* v, f32x4_t* hi_out, f32x4_t* lo_out) {
-  split8_rne(v, hi_out, lo_out);  // common.h
+__device__ inline void enc_split8(const float* v, f32x4_t* hi_out, f32x4_t* lo_out,
+                                  float* sat = nullptr) {
+  split8_rne(v, hi_out, lo_out, sat);  // common.h
 }
 
 // split-format groups [hi x8 | lo x8] -> 8 fp32 values each
@@ -465,10 +475,12 @@ __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups
                                         float m2, float s0, float s1, float s2,
                                         float* __restrict__ out,
                                         const void* __restrict__ mul = nullptr,
-                                        int mul_u8 = 1) {
+                                        int mul_u8 = 1, int* __restrict__ poison = nullptr,
+                                        unsigned* __restrict__ status = nullptr) {
 #pragma clang fp contract(off)  // see preprocess_kernel
   const float inv255 = (float)(1.0 / 255.0);
   const long hw = (long)H * W;
+  float sat = 0.f;
   for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n_groups;
        q += (long)gridDim.x * blockDim.x) {
     const int p = q % G;
@@ -498,12 +510,20 @@ __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups
       }
       v[4 * h] = a; v[4 * h + 1] = b; v[4 * h + 2] = cc; v[4 * h + 3] = 0.f;
     }
+    if constexpr (sizeof(T) != 1) {
+      if (poison != nullptr &&
+          !(fabsf(v[0]) + fabsf(v[1]) + fabsf(v[2]) + fabsf(v[4]) + fabsf(v[5]) + fabsf(v[6]) < INFINITY)) {
+        poison[n] = 1;  // (see preprocess_kernel)
+        if (status) atomicOr(status, 2u /* MILAN_STATUS_NONFINITE_INPUT */);
+      }
+    }
     f32x4_t hi, lo;
-    enc_split8(v, &hi, &lo);
+    enc_split8(v, &hi, &lo, &sat);
     f32x4_t* o = reinterpret_cast<f32x4_t*>(out + q * 8);
     o[0] = hi;
     o[1] = lo;
   }
+  report_saturation(status, sat);
 }
 
 // Same, 8 channels per thread, output in split-f16 format (gemm.hip).
@@ -511,9 +531,11 @@ __global__ void bn_relu_maxpool_split_kernel(const float* __restrict__ x, int n,
                                              int H, int W, int C, int Ho, int Wo,
                                              const float* __restrict__ scale,
                                              const float* __restrict__ shift,
-                                             float* __restrict__ y) {
+                                             float* __restrict__ y,
+                                             unsigned* __restrict__ status) {
   const int C8 = C >> 3;
   const long total = (long)n * Ho * Wo * C8;
+  float sat = 0.f;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const int c8 = idx % C8;
@@ -545,11 +567,12 @@ __global__ void bn_relu_maxpool_split_kernel(const float* __restrict__ x, int n,
       }
     }
     f32x4_t hi4, lo4;
-    enc_split8(best, &hi4, &lo4);
+    enc_split8(best, &hi4, &lo4, &sat);
     float* d = y + idx * 8;
     *reinterpret_cast<f32x4_t*>(d) = hi4;
     *reinterpret_cast<f32x4_t*>(d + 4) = lo4;
   }
+  report_saturation(status, sat);
 }
 
 // ---------------------------------------------------------------------------
@@ -661,7 +684,7 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
     const float* __restrict__ tap, int P, int C, int level, Levels lv,
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
     const int* __restrict__ list_n, float* __restrict__ features, int fstride,
-    int col_off, int img0, float inv_scale) {
+    int col_off, int img0, float inv_scale, const int* __restrict__ poison = nullptr) {
   __shared__ float part[4][64];
   // `tap` points at image img0 of the batch; lists / features are indexed by
   // the absolute image number
@@ -697,10 +720,37 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
   __syncthreads();
   if (phase == 0 && c < C) {
     // (inv_scale: 1 / activation scale of a split-format tap, an exact power of two)
-    features[(long)img * fstride + col_off + c] =
-        ((part[0][threadIdx.x] + part[1][threadIdx.x]) +
-         (part[2][threadIdx.x] + part[3][threadIdx.x])) * inv_scale;
+    float f = ((part[0][threadIdx.x] + part[1][threadIdx.x]) +
+               (part[2][threadIdx.x] + part[3][threadIdx.x])) * inv_scale;
+    // an image with a non-finite pixel: every level of the reference's pyramid is NaN
+    if (poison != nullptr && poison[img]) f = __builtin_nanf("");
+    features[(long)img * fstride + col_off + c] = f;
   }
+}
+
+// rows of poisoned images -> NaN (SpatialConvEncoder read-out; see preprocess_kernel)
+__global__ void poison_fill_kernel(float* __restrict__ out, long per_image, int n,
+                                   const int* __restrict__ poison) {
+  const long total = (long)n * per_image;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x)
+    if (poison[i / per_image]) out[i] = __builtin_nanf("");
+}
+
+// calibration (milan_encoder_absmax): max |x| of a trunk activation tensor, fp32 mode
+__global__ void act_absmax_kernel(const float* __restrict__ x, long n,
+                                  unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float a = fabsf(x[i]);
+    m = (a > m || a != a) ? a : m;   // (NaN propagates into the maximum)
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(m, o);
+    m = (t > m || t != t) ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
 // ---------------------------------------------------------------------------
@@ -714,6 +764,7 @@ struct EncPlan {
   int *list_idx, *list_n;
   float* list_w;
   int* bbox;  // [n][4]: level-0 bounding box of the listed pixels
+  int* poison;  // [n]: 1 = the image holds a non-finite pixel (float inputs only)
 };
 
 static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
@@ -758,6 +809,7 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   pl->list_w = a.get<float>((size_t)n * lv.per_image);
   pl->list_n = a.get<int>((size_t)n * 5);
   pl->bbox = a.get<int>((size_t)n * 4);
+  pl->poison = a.get<int>((size_t)n);
   return 0;
 }
 
@@ -894,6 +946,16 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                 ws.size);
   const int wd = c->d.trunk_width;
   const int F = c->d.feature_size;
+  // float inputs can carry NaN / Inf pixels (uint8 ones cannot): image-level poison flags
+  int* const poison = image_dtype == MILAN_DTYPE_F32 ? pl.poison : nullptr;
+  // calibration pass (milan_encoder_absmax): max |x| over every activation tensor
+  auto track = [&](const float* t, long count) -> int {
+    if (c->calib == nullptr || count <= 0) return 0;
+    const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    hipLaunchKernelGGL(act_absmax_kernel, dim3(blocks), dim3(256), 0, s, t, count, c->calib);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
 
   // 1. masks -> per-level normalised sparse weight lists
   std::optional<StageScope> stage;  // current profiling region (RAII)
@@ -927,14 +989,15 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     const float s0 = c->stdv[0], s1 = c->stdv[1], s2 = c->stdv[2];
     const void* mul = spatial ? masks : nullptr;  // spatial mode: x * mask
     const int mul_u8 = mask_dtype == MILAN_DTYPE_U8;
+    if (poison) MILAN_CHECK_HIP(hipMemsetAsync(poison, 0, sizeof(int) * (size_t)n, s));
     if (pair_stem && image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_pairs_kernel<uint8_t>, dim3(blocks),
                          dim3(256), 0, s, (const uint8_t*)images, np, H, W, G,
-                         m0, m1, m2, s0, s1, s2, pl.in4, mul, mul_u8);
+                         m0, m1, m2, s0, s1, s2, pl.in4, mul, mul_u8, nullptr, c->status);
     else if (pair_stem)
       hipLaunchKernelGGL(preprocess_pairs_kernel<float>, dim3(blocks), dim3(256),
                          0, s, (const float*)images, np, H, W, G, m0, m1, m2, s0,
-                         s1, s2, pl.in4, mul, mul_u8);
+                         s1, s2, pl.in4, mul, mul_u8, poison, c->status);
     else if (image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
                          s, (const uint8_t*)images, np, H * W, m0, m1, m2, s0, s1,
@@ -942,7 +1005,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     else
       hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
                          (const float*)images, np, H * W, m0, m1, m2, s0, s1, s2,
-                         (float4*)pl.in4, mul, mul_u8);
+                         (float4*)pl.in4, mul, mul_u8, poison, c->status);
     MILAN_CHECK_HIP(hipGetLastError());
   }
   stage.reset();
@@ -959,11 +1022,11 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col_off, img0,
-                         1.f / c->act_scale);
+                         1.f / c->act_scale, poison);
     else
       hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off, img0, 1.f);
+                         pl.list_w, pl.list_n, features, F, col_off, img0, 1.f, poison);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   };
@@ -1014,7 +1077,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (split)
       hipLaunchKernelGGL(bn_relu_maxpool_split_kernel, dim3(blocks), dim3(256), 0,
                          s, pl.raw, n, pl.h1, pl.w1, wd, pl.hp, pl.wp,
-                         c->bn1_scale_s, c->bn1_shift_s, pl.x0);
+                         c->bn1_scale_s, c->bn1_shift_s, pl.x0, c->status);
     else
       hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, s,
                          (const float4*)pl.raw, n, pl.h1, pl.w1, wd / 4, pl.hp,
@@ -1023,8 +1086,17 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     MILAN_CHECK_HIP(hipGetLastError());
     stage.reset();
     }
+    if (c->calib && !split) {
+      MILAN_TRY(track(pl.x0, (long)n * pl.hp * pl.wp * wd));
+    }
   }
 
+  // (calibration: every conv output of the fp32 pass is folded into the running maximum)
+  auto gemm_t = [&](const GemmArgs& g) -> int {
+    MILAN_TRY(launch_gemm(g, s));
+    if (c->calib && !split) MILAN_TRY(track(g.C, (long)g.M * g.N));
+    return 0;
+  };
   // 4. bottleneck stages; tap after each stage
   float *x = pl.x0, *y = pl.x1;
   int h = pl.hp, w = pl.wp, col = wd;
@@ -1042,25 +1114,25 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         // BasicBlock (resnet18/34): relu(bn2(conv2(relu(bn1(conv1(x))))) + id)
         GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
                                 c->zero, &h1, &w1, split);
-        MILAN_TRY(launch_gemm(g1, s));
+        MILAN_TRY(gemm_t(g1));
         const float* identity = x;
         if (b.has_down) {
           int hd, wdn;
           GemmArgs gd = conv_args(b.down, x, n, h, w, pl.ds, EPI_BIAS, nullptr,
                                   c->zero, &hd, &wdn, split);
-          MILAN_TRY(launch_gemm(gd, s));
+          MILAN_TRY(gemm_t(gd));
           identity = pl.ds;
         }
         GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, y, EPI_BIAS_RES_RELU,
                                 identity, c->zero, &h3, &w3, split);
-        MILAN_TRY(launch_gemm(g2, s));
+        MILAN_TRY(gemm_t(g2));
         float* tmp = x; x = y; y = tmp;
         h = h3; w = w3;
         continue;
       }
       GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
                               c->zero, &h1, &w1, split);
-      if (!t1_ready) MILAN_TRY(launch_gemm(g1, s));
+      if (!t1_ready) MILAN_TRY(gemm_t(g1));
       t1_ready = false;
       GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU,
                               nullptr, c->zero, &h2, &w2, split);
@@ -1086,7 +1158,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         ca.out = pl.t2; ca.zero = c->zero; ca.n = n; ca.h = h1; ca.w = w1;
         MILAN_TRY(launch_conv3_p64(ca, s));
       } else {
-        MILAN_TRY(launch_gemm(g2, s));
+        MILAN_TRY(gemm_t(g2));
       }
       const float* identity = x;
       // Expand conv of this block + reduce conv of the next one in ONE launch: the
@@ -1143,7 +1215,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         g3.a2_pix_stride = b.down.cin;
         g3.a2_img_stride = (long)h * w * b.down.cin;
         g3.flop_k = b.c3.K + b.down.K;
-        MILAN_TRY(launch_gemm(g3, s));
+        MILAN_TRY(gemm_t(g3));
         float* tmp = x; x = y; y = tmp;
         h = h3; w = w3;
         continue;
@@ -1152,12 +1224,12 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         int hd, wdn;
         GemmArgs gd = conv_args(b.down, x, n, h, w, pl.ds, EPI_BIAS, nullptr,
                                 c->zero, &hd, &wdn, split);
-        MILAN_TRY(launch_gemm(gd, s));
+        MILAN_TRY(gemm_t(gd));
         identity = pl.ds;
       }
       GemmArgs g3 = conv_args(b.c3, pl.t2, n, h2, w2, y, EPI_BIAS_RES_RELU,
                               identity, c->zero, &h3, &w3, split);
-      MILAN_TRY(launch_gemm(g3, s));
+      MILAN_TRY(gemm_t(g3));
       float* tmp = x; x = y; y = tmp;
       h = h3; w = w3;
     }
@@ -1182,7 +1254,36 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       MILAN_CHECK_HIP(hipMemcpyAsync(spatial_out, x, sizeof(float) * rows * C,
                                      hipMemcpyDeviceToDevice, s));
     }
+    if (poison) {
+      const long per_image = (long)h * w * C;
+      const long total = (long)n * per_image;
+      const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+      hipLaunchKernelGGL(poison_fill_kernel, dim3(blocks), dim3(256), 0, s, spatial_out,
+                         per_image, n, poison);
+      MILAN_CHECK_HIP(hipGetLastError());
+    }
   }
+  return 0;
+}
+
+// milan_set_act_scale_log2: the pre-multiplied copies of every folded bias / bn1 vector are
+// rewritten in place for the new activation scale (exact: a power of two)
+int encoder_rescale(milan_ctx* c, hipStream_t s) {
+  auto redo = [&](const float* src, float* dst, int n) -> int {
+    if (!src || !dst) return 0;
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src,
+                       c->act_scale, n, dst);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+  if (c->stem.w) {
+    MILAN_TRY(redo(c->bn1_scale, c->bn1_scale_s, c->stem.cout));
+    MILAN_TRY(redo(c->bn1_shift, c->bn1_shift_s, c->stem.cout));
+  }
+  for (int li = 0; li < 4; ++li)
+    for (Bottleneck& b : c->blocks[li])
+      for (ConvW* w : {&b.c1, &b.c2, &b.c3, &b.down, &b.c3d})
+        MILAN_TRY(redo(w->bias, w->bias_s, w->cout));
   return 0;
 }
 
@@ -1228,9 +1329,11 @@ __global__ void maxpool3s2_f32_kernel(const float4* __restrict__ x, int n, int H
 template <bool IN_SPLIT>
 __global__ void maxpool3s2_split_kernel(const float* __restrict__ x, int n, int H,
                                         int W, int C, int Ho, int Wo, int pad,
-                                        float* __restrict__ y) {
+                                        float* __restrict__ y,
+                                        unsigned* __restrict__ status) {
   const int C8 = C >> 3;
   const long total = (long)n * Ho * Wo * C8;
+  float sat = 0.f;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const int c8 = idx % C8;
@@ -1265,11 +1368,12 @@ __global__ void maxpool3s2_split_kernel(const float* __restrict__ x, int n, int 
       }
     }
     f32x4_t hi4, lo4;
-    enc_split8(best, &hi4, &lo4);
+    enc_split8(best, &hi4, &lo4, &sat);
     float* d = y + idx * 8;
     *reinterpret_cast<f32x4_t*>(d) = hi4;
     *reinterpret_cast<f32x4_t*>(d + 4) = lo4;
   }
+  report_saturation(status, sat);
 }
 
 struct AlexPlan {
@@ -1376,11 +1480,11 @@ static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
     else if (in_split)
       hipLaunchKernelGGL(maxpool3s2_split_kernel<true>, dim3(blocks), dim3(256),
                          0, s, pl.a[l], n, pl.lv.h[l], pl.lv.w[l], C, pl.hq[l],
-                         pl.wq[l], 0, pl.q[l]);
+                         pl.wq[l], 0, pl.q[l], c->status);
     else
       hipLaunchKernelGGL(maxpool3s2_split_kernel<false>, dim3(blocks), dim3(256),
                          0, s, pl.a[l], n, pl.lv.h[l], pl.lv.w[l], C, pl.hq[l],
-                         pl.wq[l], 0, pl.q[l]);
+                         pl.wq[l], 0, pl.q[l], c->status);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   };

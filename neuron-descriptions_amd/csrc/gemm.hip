@@ -112,8 +112,8 @@ __device__ inline f16x8 as_f16x8(f32x4 v) {
 }
 
 // 8 fp32 <-> (hi, lo) f16x8 pair: common.h (split8_rne / join8_exact)
-__device__ inline void split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
-  split8_rne(v, hi_out, lo_out);
+__device__ inline void split8(const float* v, f32x4* hi_out, f32x4* lo_out, float* sat = nullptr) {
+  split8_rne(v, hi_out, lo_out, sat);
 }
 __device__ inline void join8(f32x4 hi, f32x4 lo, float* v) { join8_exact(hi, lo, v); }
 
@@ -229,6 +229,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
     // gated context, written straight into the LSTM's split-format input)
     constexpr bool SIG = EPI == EPI_BIAS_SIGMUL;
     constexpr bool RES = (EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_ADD || SIG);
+    float sat = 0.f;  // running max of the clamped magnitudes (common.h: saturation is loud)
     f32x4 res[RES ? 2 : 1][4][2];
     auto load_res = [&](int i, f32x4 (&r)[4][2]) {
 #pragma unroll
@@ -281,15 +282,16 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
           }
           f32x4 hi, lo;
           if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU)
-            split8_relu_rne(v, &hi, &lo);   // (ReLU folded into the clamp)
+            split8_relu_rne(v, &hi, &lo, &sat);   // (ReLU folded into the clamp)
           else
-            split8(v, &hi, &lo);
+            split8(v, &hi, &lo, &sat);
           float* cp = g.C + (long)m * g.ldc + n;
           *reinterpret_cast<f32x4*>(cp) = hi;
           *reinterpret_cast<f32x4*>(cp + 4) = lo;
         }
       }
     }
+    report_saturation(g.status, sat);
   };
 
   // (4) LSTM cell on gate-interleaved columns: the wave's 64 columns are
@@ -2200,9 +2202,10 @@ static int launch_conv3x3(const GemmArgs& g, hipStream_t s) {
 // ---------------------------------------------------------------------------
 __global__ void f32_to_split_kernel(const float* __restrict__ src, long lds_,
                                     float* __restrict__ dst, long ldd, long rows,
-                                    int K, float scale) {
+                                    int K, float scale, unsigned* status) {
   const int g8 = K >> 3;
   const long total = rows * g8;
+  float sat = 0.f;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const long r = idx / g8;
@@ -2214,11 +2217,12 @@ __global__ void f32_to_split_kernel(const float* __restrict__ src, long lds_,
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = a[e] * scale; v[4 + e] = b[e] * scale; }
     f32x4 hi, lo;
-    split8(v, &hi, &lo);
+    split8(v, &hi, &lo, &sat);
     float* d = dst + r * ldd + q * 8;
     *reinterpret_cast<f32x4*>(d) = hi;
     *reinterpret_cast<f32x4*>(d + 4) = lo;
   }
+  report_saturation(status, sat);
 }
 
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
@@ -2230,7 +2234,7 @@ int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(f32_to_split_kernel, dim3((int)blocks), dim3(256), 0, s, src,
-                     ld_src, dst, ld_dst, rows, K, scale);
+                     ld_src, dst, ld_dst, rows, K, scale, status_word());
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -2261,6 +2265,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 struct ProfRec {
   hipEvent_t a = nullptr, b = nullptr;
   int stage = 0;
+  int kernel = 0;     // MILAN_KERNEL_* family of a GEMM-class launch
   bool gemm = false;
   double flops = 0.0;
   double bytes = 0.0;  // algorithmic HBM bytes of a GEMM launch
@@ -2295,8 +2300,17 @@ struct Profiler {
   std::vector<ProfRec> rec;
   size_t used = 0;
   int stage = MILAN_STAGE_OTHER;
+  ProfRec* open = nullptr;  // the GEMM-class record being launched (profile_tag_kernel)
 };
 static Profiler g_prof;
+
+// ---- status word of the calling context (common.h) ------------------------------------
+static thread_local unsigned* t_status_word = nullptr;
+void set_status_word(unsigned* word) { t_status_word = word; }
+unsigned* status_word() { return t_status_word; }
+void profile_tag_kernel(int family) {
+  if (g_prof.on && g_prof.open) g_prof.open->kernel = family;
+}
 
 static ProfRec* prof_next() {
   if (g_prof.used == g_prof.rec.size()) {
@@ -2314,17 +2328,21 @@ void* gemm_profile_begin(double flops, double bytes, hipStream_t s) {
   ProfRec* e = prof_next();
   if (!e) return nullptr;
   e->stage = g_prof.stage; e->gemm = true; e->flops = flops; e->bytes = bytes;
+  e->kernel = MILAN_KERNEL_OTHER;
+  g_prof.open = e;
   (void)hipEventRecord(e->a, s);
   return e;
 }
 void gemm_profile_end(void* rec, hipStream_t s) {
   if (rec) (void)hipEventRecord(static_cast<ProfRec*>(rec)->b, s);
+  g_prof.open = nullptr;
 }
 
 int gemm_profile_enable(int enable) {
   g_prof.on = enable != 0;
   g_prof.used = 0;
   g_prof.stage = MILAN_STAGE_OTHER;
+  g_prof.open = nullptr;
   return 0;
 }
 
@@ -2362,6 +2380,21 @@ int gemm_profile_read(double* ms, double* flops, long long* launches) {
   if (ms) *ms = total;
   if (flops) *flops = fl;
   if (launches) *launches = n;
+  return 0;
+}
+
+// table[family][0..3] = ms, algorithmic flops, launches, algorithmic HBM bytes
+int profile_read_kernels(double* table) {
+  MILAN_CHECK_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < MILAN_KERNEL_COUNT * 4; ++i) table[i] = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    const ProfRec& r = g_prof.rec[i];
+    if (!r.gemm || r.kernel < 0 || r.kernel >= MILAN_KERNEL_COUNT) continue;
+    float t = 0.f;
+    MILAN_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    double* row = table + r.kernel * 4;
+    row[0] += t; row[1] += r.flops; row[2] += 1.0; row[3] += r.bytes;
+  }
   return 0;
 }
 
@@ -2435,6 +2468,7 @@ static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("MILAN_PP_PERSIST"); persist = e ? atoi(e) : 0; }
   const bool walk = persist && (persist != 2 || g.K <= 512) && grid > ncus;
+  profile_tag_kernel(BNW == 256 ? MILAN_KERNEL_PP32_256 : MILAN_KERNEL_PP32_128);
   if (BNW == 256 && !walk) {
     auto kern = igemm_split16_pp32_kernel;
     MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
@@ -2523,13 +2557,7 @@ static int launch_split16(const GemmArgs& g, hipStream_t s) {
       if (on && g.Kp / 16 >= STAGES - 1 && tiles_m * tiles_n > cus) {
         const size_t lds = size_t(STAGES) * (BM + BN) * 16 * sizeof(float);
         auto kern = igemm_split16_linp_kernel<STAGES>;
-        static bool attr_set = false;
-        if (!attr_set) {
-          MILAN_CHECK_HIP(hipFuncSetAttribute(
-              reinterpret_cast<const void*>(kern),
-              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          attr_set = true;
-        }
+        MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
         hipLaunchKernelGGL(kern, dim3(cus), dim3(512), lds, s, g, tiles_m, tiles_n);
         MILAN_CHECK_HIP(hipGetLastError());
         return 0;
@@ -2600,6 +2628,7 @@ static int env_tile_override(int, int) { return 0; }
 
 static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
   const bool cin32 = (g.Cin % 32 == 0);
+  if (g.status == nullptr) g.status = status_word();
   if (g.tile_hint == 0) g.tile_hint = env_tile_hint();
   if (const int o = env_tile_override(g.N, g.K)) g.tile_hint = o;
   {
@@ -2743,10 +2772,13 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
   MILAN_REQUIRE(e != nullptr, MILAN_ERR_STATE, "profiler: cannot create events");
   e->stage = g_prof.stage;
   e->gemm = true;
+  e->kernel = g.a_split ? MILAN_KERNEL_SPLIT_OTHER : MILAN_KERNEL_F32;
   e->flops = 2.0 * (double)g.M * (double)g.N * (double)(g.flop_k > 0 ? g.flop_k : g.K);
   e->bytes = gemm_algorithmic_bytes(g);
+  g_prof.open = e;
   MILAN_CHECK_HIP(hipEventRecord(e->a, s));
   const int r = launch_gemm_impl(g, s);
+  g_prof.open = nullptr;
   MILAN_CHECK_HIP(hipEventRecord(e->b, s));
   return r;
 }

@@ -74,8 +74,8 @@ struct StemTile {
 
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-__device__ inline void stem_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
-  split8_rne(v, hi_out, lo_out);  // common.h
+__device__ inline void stem_split8(const float* v, f32x4* hi_out, f32x4* lo_out, float* sat) {
+  split8_rne(v, hi_out, lo_out, sat);  // common.h
 }
 
 }  // namespace
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
   constexpr int kMBW = T::kMBW;
   extern __shared__ __attribute__((aligned(16))) char stem_smem[];
   float* stg = reinterpret_cast<float*>(stem_smem + 2 * kInBytes);  // [32 kMB][kSRow]
+  float sat = 0.f;  // (common.h: saturation of the split clamp is loud)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
         for (int e = 0; e < 8; ++e)
           best[e] = fmaxf(__builtin_fmaf(best[e] * sg[e], sc[e], sh[e]), 0.f);
         f32x4 hi4, lo4;
-        stem_split8(best, &hi4, &lo4);
+        stem_split8(best, &hi4, &lo4, &sat);
         float* d = a.y + ((((long)img * a.hp + ho) * a.wp + wo) * 8 + c8) * 8;
         *reinterpret_cast<f32x4*>(d) = hi4;
         *reinterpret_cast<f32x4*>(d + 4) = lo4;
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
     }
     have = nhave; img = nimg; ta = nta; tb = ntb;
   }
+  report_saturation(a.status, sat);
 }
 
 bool stem_fused_supported(int cout, int Kp) { return cout == 64 && Kp == 224; }
@@ -327,21 +329,24 @@ int launch_stem_fused(const StemArgs& a, hipStream_t s) {
                 MILAN_ERR_ARG, "stem: missing operand");
   int cus = 0;
   MILAN_TRY(device_cus8(&cus));
+  StemArgs aa = a;
+  if (aa.status == nullptr) aa.status = status_word();
   // algorithmic work: 7x7x3 taps per conv1 output; bytes: input groups once, raw
   // fp32 out, pooled split out
   const double px1 = (double)a.n * a.h1 * a.w1, pxp = (double)a.n * a.hp * a.wp;
   void* rec = gemm_profile_begin(
       2.0 * px1 * 64 * 147,
       32.0 * a.n * a.H * a.G + (a.raw ? 256.0 * px1 : 0.0) + 256.0 * pxp, s);
+  profile_tag_kernel(MILAN_KERNEL_STEM);
   int r;
 #if MILAN_EXPERIMENTS
   // MILAN_STEM_TILE=0: 3 x 8 pooled pixels per 4-wave workgroup, two per CU (measured
   // slower: 5.8 against 5.3 ms per 256 neurons, profiles/r3_experiments.txt)
   static const int variant = getenv("MILAN_STEM_TILE") ? atoi(getenv("MILAN_STEM_TILE")) : 1;
-  if (variant == 0) r = launch_stem_cfg<3, 8, 4>(a, cus, s);
+  if (variant == 0) r = launch_stem_cfg<3, 8, 4>(aa, cus, s);
   else
 #endif
-  r = launch_stem_cfg<7, 8, 8>(a, cus, s);
+  r = launch_stem_cfg<7, 8, 8>(aa, cus, s);
   gemm_profile_end(rec, s);
   return r;
 }

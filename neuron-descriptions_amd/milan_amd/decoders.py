@@ -137,9 +137,11 @@ class Decoder(nn.Module):
         # rows fill whole rounds of GEMM tiles (+2.6 % over 256, measured) and
         # take 154 GB of activation workspace; lower it on a shared GPU
         self.chunk_size = 640
-        # 'f32' (exact fp32 MFMA, the reference's arithmetic) or 'split_f16'
-        # (3 x f16 MFMA on (hi,lo) operand pairs: fp32-class error, ~2.2x
-        # faster); see DESIGN.md section 4.2.  MILAN_PRECISION sets the default.
+        # 'f32' (exact fp32 MFMA, the reference's arithmetic), 'split_f16'
+        # (3 x f16 MFMA on (hi,lo) operand pairs: fp32-class error, ~2.7x
+        # faster; raises FloatingPointError if an activation leaves its range) or
+        # 'auto' (split_f16, and a call that saturates is rerun in f32); see
+        # DESIGN.md section 4.2.  MILAN_PRECISION sets the default.
         import os
         self.precision = os.environ.get('MILAN_PRECISION', 'f32')
         # replay each distinct decode pass from a captured hipGraph (helps
@@ -209,11 +211,29 @@ class Decoder(nn.Module):
                 self._ctx.close()
             self._ctx = hip.Context(dims, sd, device)
             self._ctx_key = key
-        if self._ctx.precision != self.precision:
-            self._ctx.set_precision(self.precision)
+        # 'auto' = split_f16 that falls back to f32 for a call whose activations left
+        # the split format's range (hip.Context._guarded); otherwise saturation raises
+        want = 'split_f16' if self.precision == 'auto' else self.precision
+        if self._ctx.precision != want:
+            self._ctx.set_precision(want)
+        self._ctx.on_saturation = 'f32' if self.precision == 'auto' else 'raise'
         if bool(getattr(self._ctx, '_graphs', False)) != bool(self.use_graphs):
             self._ctx.enable_graphs(self.use_graphs)
         return self._ctx
+
+    def calibrate(self, images: torch.Tensor, headroom: float = 8.0) -> int:
+        """Choose the split-f16 trunk's activation scale from a sample of exemplar
+        images ((M,3,H,W) or (N,k,3,H,W), uint8 or float): the trunk runs once in the
+        exact-fp32 mode, the largest |activation| of any tensor it stores is observed,
+        and the scale becomes the largest power of two that leaves `headroom` x that
+        maximum below the f16 range.  Returns log2 of the scale.  Not in the reference
+        (its fp32 needs none); with the default scale 2^5 activations beyond 2047 raise
+        FloatingPointError instead of being clamped silently."""
+        if not self._has_hip_encoder():
+            raise ValueError('calibrate() needs the native pyramid encoder')
+        if images.dim() == 5:
+            images = images.reshape(-1, *images.shape[2:])
+        return self._context().calibrate(images, headroom)
 
     # -- forward -------------------------------------------------------------------
     def forward(self,

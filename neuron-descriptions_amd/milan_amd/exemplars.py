@@ -599,7 +599,10 @@ def _load_cache(path: Optional[pathlib.Path], args: Dict[str, Any]):
             return None
         have = state[key]
         have = have.item() if getattr(have, 'shape', None) == () else have
-        if have != value:
+        if isinstance(have, numpy.ndarray) or isinstance(value, numpy.ndarray):
+            if not numpy.array_equal(numpy.asarray(have), numpy.asarray(value)):
+                return None
+        elif have != value:
             return None
     return state
 
@@ -690,12 +693,18 @@ def compute(compute_topk_and_quantile: Callable[..., Any],
 
     # ---- pass 1: tally (tally.tally_topk_and_quantile, tally.py:199-222) ----
     topk, rq = RunningTopK(k=k), RunningQuantile(r=4096)
-    tally_args = dict(sample_size=None, k=k, r=4096)
+    # the unit list is part of the cache key (a tally of ANOTHER unit list of
+    # the same length, or a subset tally reused for an all-units run, must not be adopted);
+    # `units=None` is recorded as the empty list
+    tally_args = dict(sample_size=None, k=k, r=4096,
+                      units=numpy.array(units if units is not None else [],
+                                        dtype=numpy.int64))
     cached = _load_cache(tally_cache, tally_args)
-    if cached is not None and units is not None and (
+    if cached is not None and (
             'rtk.top_data' not in cached or
-            cached['rtk.top_data'].shape[0] != len(units)):
-        cached = None  # a tally of another unit list: recompute
+            (units is not None and
+             cached['rtk.top_data'].shape[0] != len(units))):
+        cached = None  # not a tally this run can adopt: recompute
     if cached is not None:
         topk.set_state_dict(_pull_prefix('rtk', cached))
         rq.set_state_dict(_pull_prefix('rq', cached))

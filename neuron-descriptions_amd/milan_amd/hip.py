@@ -25,6 +25,11 @@ PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
 PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16}
 FUSE_CHAIN, FUSE_CHAIN_WIDE, FUSE_STEM, FUSE_CONV3 = 1, 2, 4, 8  # milan_set_fusion flags (include/milan_hip.h)
 SKETCH_COMPACT, SKETCH_INSERT, SKETCH_MOVE, SKETCH_HALVE = 0, 1, 2, 3
+# milan_status bits (include/milan_hip.h)
+STATUS_SATURATED, STATUS_NONFINITE_INPUT = 1, 2
+# enum milan_kernel_family (milan_profile_read_kernels)
+KERNEL_FAMILIES = ('other', 'pp32_256', 'pp32_128', 'split_other', 'f32', 'chain',
+                   'chain_wide', 'stem', 'conv3')
 
 
 class SketchOp(ctypes.Structure):
@@ -69,7 +74,7 @@ class Dims(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 6  # MILAN_ABI_VERSION this binding was written against
+ABI_VERSION = 7  # MILAN_ABI_VERSION this binding was written against
 
 # milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
 TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET, TRUNK_NONE = 0, 1, 2, 3
@@ -126,6 +131,12 @@ SIGNATURES = {
         ctypes.POINTER(ctypes.c_longlong)
     ]),
     'milan_profile_read_stages': (_I, [ctypes.POINTER(ctypes.c_double)]),
+    'milan_profile_read_kernels': (_I, [ctypes.POINTER(ctypes.c_double)]),
+    'milan_status': (_I, [_P, ctypes.POINTER(ctypes.c_uint32), _I, _P]),
+    'milan_set_act_scale_log2': (_I, [_P, _I, _P]),
+    'milan_get_act_scale_log2': (_I, [_P]),
+    'milan_encoder_absmax':
+        (_I, [_P, _P, _I, _I, _I, _I, ctypes.POINTER(_F), _P, _SZ, _P]),
     'milan_exemplar_topk_update':
         (_I, [_P, _I, _I, _I, _P, _I, _I64, _I, _I, _P, _P, _P, _P]),
     'milan_exemplar_sketch_append':
@@ -319,6 +330,11 @@ class Context:
                                                 _stream(self.device)))
             del keep
         self._ws: Optional[torch.Tensor] = None
+        # what a saturated split-f16 value does (see `_guarded`): 'raise' (default),
+        # 'f32' (rerun the call in the exact-fp32 mode: Decoder.precision = 'auto') or
+        # 'ignore' (the caller reads `status()` itself, e.g. once after a timed region)
+        self.on_saturation = os.environ.get('MILAN_ON_SATURATION', 'raise')
+        self.saturation_fallbacks = 0
         _LIVE_CONTEXTS.add(self)
         warn_if_gpu_is_shared()  # (after the context exists: this process has queues)
         if os.environ.get('MILAN_CHAIN'):  # A/B timing (tools/ab_env.sh): flag bits
@@ -326,7 +342,10 @@ class Context:
             self.set_fusion(chain=bool(bits & 1), wide=bool(bits & 2), stem=bool(bits & 4),
                             conv3=bool(bits & 8))
         default = os.environ.get('MILAN_PRECISION')
-        if default:
+        if default == 'auto':
+            self.set_precision('split_f16')
+            self.on_saturation = 'f32'
+        elif default:
             self.set_precision(default)
 
     # -- hipGraph replay of the decode stage ------------------------------------
@@ -381,6 +400,96 @@ class Context:
     def precision(self) -> str:
         code = self.lib.milan_get_precision(self._h)
         return {v: k for k, v in PRECISIONS.items()}[code]
+
+    # -- split-f16 fails loudly ------------------------------------------------------
+    def status(self, clear: bool = True) -> int:
+        """The context's device status word (STATUS_* bits), read back through a stream
+        synchronisation; `clear` resets it."""
+        flags = ctypes.c_uint32(0)
+        with torch.cuda.device(self.device):
+            _check(self.lib.milan_status(self._h, ctypes.byref(flags), int(clear),
+                                         _stream(self.device)))
+        return int(flags.value)
+
+    @property
+    def act_scale_log2(self) -> int:
+        return int(self.lib.milan_get_act_scale_log2(self._h))
+
+    def set_act_scale_log2(self, k: int) -> None:
+        """Activation scale 2^k of the split-f16 trunk (0..10): `hi` saturates at
+        65504 / 2^k, `lo` keeps full precision down to activations of 0.125 / 2^k."""
+        with torch.cuda.device(self.device):
+            _check(self.lib.milan_set_act_scale_log2(self._h, int(k),
+                                                     _stream(self.device)))
+
+    def encoder_absmax(self, images: torch.Tensor) -> float:
+        """Largest |activation| any tensor of the ResNet trunk holds for `images`
+        ((M,3,H,W), uint8 or float), measured in the exact-fp32 mode."""
+        m, ch, h, w = images.shape
+        if ch != 3:
+            raise ValueError(f'images must have 3 channels, got {ch}')
+        idt = DTYPE_U8 if images.dtype == torch.uint8 else DTYPE_F32
+        images = _dev(images, self.device, None if idt == DTYPE_U8 else torch.float32)
+        ws = self.workspace(m or 1, 1, max(h, w), 1, 1)
+        out = _F(0.0)
+        with torch.cuda.device(self.device):
+            _check(self.lib.milan_encoder_absmax(self._h, images.data_ptr(), idt, m, h, w,
+                                                 ctypes.byref(out), ws.data_ptr(),
+                                                 ws.numel(), _stream(self.device)))
+        return float(out.value)
+
+    def calibrate(self, images: torch.Tensor, headroom: float = 8.0) -> int:
+        """Pick the split trunk's activation scale from a sample: the largest power of
+        two that keeps `headroom` x the observed maximum below the f16 range.  Returns
+        the chosen log2 scale.  (The default 2^5 suits activations up to 2047; a
+        network whose residual stream grows beyond that needs a smaller scale, one
+        whose activations sit at 1e-3 a larger one -- DESIGN.md section 4.2.)"""
+        import math
+        amax = self.encoder_absmax(images)
+        if not math.isfinite(amax):
+            raise FloatingPointError('calibration sample produced non-finite activations')
+        k = 10 if amax <= 0 else int(math.floor(math.log2(65504.0 / (amax * headroom))))
+        k = max(0, min(10, k))
+        self.set_act_scale_log2(k)
+        return k
+
+    def _guarded(self, what: str, run, check: bool = True):
+        """Run one computing call and act on the status word it leaves behind.
+
+        MILAN_STATUS_SATURATED: a split-format value hit the +-65504 clamp -- the
+        reference's fp32 would not have, so the result is NOT returned: raise
+        FloatingPointError, or (on_saturation == 'f32') rerun the call in the exact-fp32
+        mode.  MILAN_STATUS_NONFINITE_INPUT: a float input pixel was NaN / Inf; the
+        features of its image are NaN as in the reference -- a RuntimeWarning says so."""
+        out = run()
+        if not check or self.on_saturation == 'ignore':
+            return out
+        flags = self.status(clear=True)
+        if flags & STATUS_NONFINITE_INPUT:
+            import warnings
+            warnings.warn(f'milan_amd: {what}: an input image holds NaN / Inf pixels; its '
+                          'features are NaN (as in the reference)', RuntimeWarning,
+                          stacklevel=3)
+        if flags & STATUS_SATURATED:
+            limit = 65504.0 / 2 ** self.act_scale_log2
+            msg = (f'milan_amd: {what}: a split-f16 activation exceeded {limit:g} '
+                   f'(65504 / 2^{self.act_scale_log2}) and was clamped; the exact-fp32 '
+                   "mode (precision='f32'), Decoder.precision = 'auto' or a smaller "
+                   'activation scale (Context.calibrate) avoid it')
+            if self.on_saturation != 'f32' or self.precision == 'f32':
+                raise FloatingPointError(msg)
+            import warnings
+            warnings.warn(msg + ' -- rerunning this call in f32', RuntimeWarning,
+                          stacklevel=3)
+            self.saturation_fallbacks += 1
+            saved = self.precision
+            self.set_precision('f32')
+            try:
+                out = run()
+                self.status(clear=True)
+            finally:
+                self.set_precision(saved)
+        return out
 
     def close(self) -> None:
         if getattr(self, '_h', None) is not None and self._h:
@@ -447,8 +556,9 @@ class Context:
 
     # -- operators ----------------------------------------------------------
     def encode(self, images: torch.Tensor,
-               masks: Optional[torch.Tensor]) -> torch.Tensor:
-        """(M,3,H,W) [+ (M,1,H,W)] -> (M,F).  uint8 or float inputs."""
+               masks: Optional[torch.Tensor], check: bool = True) -> torch.Tensor:
+        """(M,3,H,W) [+ (M,1,H,W)] -> (M,F).  uint8 or float inputs.  `check`: read the
+        status word afterwards (one stream synchronisation; see `_guarded`)."""
         m, ch, h, w = images.shape
         if ch != 3:
             raise ValueError(f'images must have 3 channels, got {ch}')
@@ -468,16 +578,20 @@ class Context:
                           dtype=torch.float32,
                           device=self.device)
         ws = self.workspace((m + 0) or 1, 1, max(h, w), 1, 1)
-        with torch.cuda.device(self.device):
-            _check(
-                self.lib.milan_encode(self._h, images.data_ptr(), idt,
-                                      _ptr(masks), mdt, m, h, w,
-                                      out.data_ptr(), ws.data_ptr(),
-                                      ws.numel(), _stream(self.device)))
-        return out
+
+        def run():
+            with torch.cuda.device(self.device):
+                _check(
+                    self.lib.milan_encode(self._h, images.data_ptr(), idt,
+                                          _ptr(masks), mdt, m, h, w,
+                                          out.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), _stream(self.device)))
+            return out
+
+        return self._guarded('encode', run, check)
 
     def encode_spatial(self, images: torch.Tensor,
-                       masks: Optional[torch.Tensor]) -> torch.Tensor:
+                       masks: Optional[torch.Tensor], check: bool = True) -> torch.Tensor:
         """SpatialConvEncoder: (M,3,H,W) [+ (M,1,H,W)] -> (M, h4*w4, C4)."""
         m, ch, h, w = images.shape
         if ch != 3:
@@ -504,13 +618,17 @@ class Context:
         out = torch.empty(m, h4 * w4, mult * self.dims.trunk_width,
                           dtype=torch.float32, device=self.device)
         ws = self.workspace(m or 1, 1, max(h, w), 1, 1)
-        with torch.cuda.device(self.device):
-            _check(
-                self.lib.milan_encode_spatial(self._h, images.data_ptr(), idt,
-                                              _ptr(masks), mdt, m, h, w,
-                                              out.data_ptr(), ws.data_ptr(),
-                                              ws.numel(), _stream(self.device)))
-        return out
+
+        def run():
+            with torch.cuda.device(self.device):
+                _check(
+                    self.lib.milan_encode_spatial(self._h, images.data_ptr(), idt,
+                                                  _ptr(masks), mdt, m, h, w,
+                                                  out.data_ptr(), ws.data_ptr(),
+                                                  ws.numel(), _stream(self.device)))
+            return out
+
+        return self._guarded('encode_spatial', run, check)
 
     def init_state(self, features: torch.Tensor):
         n, k, _ = features.shape
@@ -695,8 +813,11 @@ class Context:
                  group_size: int = 0,
                  want_full: bool = False,
                  want_features: bool = False,
-                 forced: Optional[torch.Tensor] = None):
-        """Fused hot path on (n,k,3,H,W) images (+ (n,k,1,H,W) masks)."""
+                 forced: Optional[torch.Tensor] = None,
+                 check: bool = True):
+        """Fused hot path on (n,k,3,H,W) images (+ (n,k,1,H,W) masks).  `check=False`
+        skips the status read (a stream synchronisation) -- the caller then reads
+        `status()` itself, as bench.py does once after its timed region."""
         n, k, ch, h, w = images.shape
         idt = DTYPE_U8 if images.dtype == torch.uint8 else DTYPE_F32
         images = _dev(images, self.device,
@@ -721,18 +842,22 @@ class Context:
                                 device=self.device)
         out['features'] = feats
         ws = self.workspace(n, k, max(h, w), beam, length)
-        with torch.cuda.device(self.device):
-            _check(
-                self.lib.milan_describe(
-                    self._h, images.data_ptr(), idt, _ptr(masks), mdt, n, k, h,
-                    w, strategy, length, beam, int(bool(mi)),
-                    float(temperature), group_size, _ptr(feats),
-                    out['tokens'].data_ptr(), out['scores'].data_ptr(),
-                    _ptr(out['predictions']), _ptr(out['attentions']),
-                    _ptr(out['beam_tokens']), _ptr(out['beam_scores']),
-                    out['out_len'].data_ptr(), ws.data_ptr(), ws.numel(),
-                    _stream(self.device)))
-        return out
+
+        def run():
+            with torch.cuda.device(self.device):
+                _check(
+                    self.lib.milan_describe(
+                        self._h, images.data_ptr(), idt, _ptr(masks), mdt, n, k, h,
+                        w, strategy, length, beam, int(bool(mi)),
+                        float(temperature), group_size, _ptr(feats),
+                        out['tokens'].data_ptr(), out['scores'].data_ptr(),
+                        _ptr(out['predictions']), _ptr(out['attentions']),
+                        _ptr(out['beam_tokens']), _ptr(out['beam_scores']),
+                        out['out_len'].data_ptr(), ws.data_ptr(), ws.numel(),
+                        _stream(self.device)))
+            return out
+
+        return self._guarded('describe', run, check)
 
 
 def profile_enable(enable: bool) -> None:
@@ -762,6 +887,16 @@ def profile_read_stages() -> Dict[str, Dict[str, float]]:
             'gemm_bytes')
     return {name: dict(zip(keys, table[i * 6:i * 6 + 6]))
             for i, name in enumerate(STAGES)}
+
+
+def profile_read_kernels() -> Dict[str, Dict[str, float]]:
+    """The same records by kernel family (enum milan_kernel_family): summed launch ms,
+    algorithmic FLOPs, launches, algorithmic HBM bytes."""
+    table = (ctypes.c_double * (len(KERNEL_FAMILIES) * 4))()
+    _check(load_library().milan_profile_read_kernels(table))
+    keys = ('ms', 'flops', 'launches', 'bytes')
+    return {name: dict(zip(keys, table[i * 4:i * 4 + 4]))
+            for i, name in enumerate(KERNEL_FAMILIES)}
 
 
 def conv2d_nhwc(x: torch.Tensor,

@@ -17,10 +17,20 @@ _BOTTLENECK = (1, 4, 8, 16, 32)   # F = 61 x width
 _BASIC = (1, 1, 2, 4, 8)          # F = 16 x width
 
 
-def _levels(f):
-    for mults in (_BOTTLENECK, _BASIC):
+_ALEXNET = (1, 3, 6, 4, 4)        # F = 18 x width (taps features.0/3/6/8/10)
+
+
+def _levels(f, family=None):
+    """Column ranges of the pyramid levels in an F-wide feature vector.  `family`
+    ('bottleneck' | 'basic' | 'alexnet') names the trunk; without it the width is inferred
+    -- 61 x w first, then 18 x w (AlexNet's 1152 = 18 x 64 is also 16 x 72: ADVICE r4), then
+    16 x w."""
+    named = {'bottleneck': _BOTTLENECK, 'basic': _BASIC, 'alexnet': _ALEXNET}
+    order = (named[family],) if family else (_BOTTLENECK, _ALEXNET, _BASIC)
+    for mults in order:
         total = sum(mults)
-        if f % total == 0:
+        # (a width is a multiple of 8 in every configuration of this repository)
+        if f % total == 0 and (family or (f // total) % 8 == 0):
             w = f // total
             edges, at = [], 0
             for m in mults:
@@ -30,14 +40,14 @@ def _levels(f):
     return [(0, f)]
 
 
-def feature_error(got, want):
+def feature_error(got, want, family=None):
     """max over pyramid levels of (max |got - want| / max |want|) and the level."""
     got = got.detach().cpu().double()
     want = want.detach().cpu().double()
     assert got.shape == want.shape, (got.shape, want.shape)
     assert torch.isfinite(got).all(), 'non-finite features'
     worst, where = 0.0, None
-    for lo, hi in _levels(want.shape[-1]):
+    for lo, hi in _levels(want.shape[-1], family):
         scale = float(want[..., lo:hi].abs().max())
         err = float((got[..., lo:hi] - want[..., lo:hi]).abs().max())
         if scale == 0.0:
@@ -48,8 +58,8 @@ def feature_error(got, want):
     return worst, where
 
 
-def assert_feature_class(got, want, bound=FEATURE_CLASS, what='features'):
-    worst, where = feature_error(got, want)
+def assert_feature_class(got, want, bound=FEATURE_CLASS, what='features', family=None):
+    worst, where = feature_error(got, want, family)
     assert worst <= bound, (
         f'{what}: max|err| {where[2]:.3g} = {worst:.3g} x scale {where[3]:.3g} '
         f'(columns {where[0]}:{where[1]}), bound {bound:g}')

@@ -426,3 +426,26 @@ def test_cache_files_replace_the_passes_over_the_dataset(tmp_path):
     exemplars.compute(tally, acts, dataset, results_dir=tmp_path / 'd',
                       clear_cache_files=True, **kwargs)
     assert dataset.reads > reads
+
+
+def test_tally_cache_is_keyed_on_the_unit_list(tmp_path):
+    """a cached tally of ANOTHER unit list of the same length, or a subset
+    tally offered to an all-units run, must be recomputed, not adopted."""
+    hip.require_device('cuda')
+    model = synthetic.exemplar_model(6, 2, 4, relu=True)
+    dataset = synthetic.exemplar_images(24, 16, 78)
+    tally, acts = cpu_model_callbacks(model, 'conv_2')
+    kwargs = dict(k=4, quantile=0.9, output_size=16, batch_size=8, image_size=16,
+                  num_workers=0, save_viz=False, save_results=False,
+                  tally_cache_file=tmp_path / 'tally.npz')
+    ds = data.TensorDataset(dataset)
+    a, _ = exemplars.compute(tally, acts, ds, units=[0, 3], **kwargs)
+    b, _ = exemplars.compute(tally, acts, ds, units=[1, 2], **kwargs)   # same length
+    fresh, _ = exemplars.compute(tally, acts, ds, units=[1, 2],
+                                 **dict(kwargs, tally_cache_file=None))
+    assert torch.equal(b.result()[0], fresh.result()[0])
+    assert not torch.equal(a.result()[0], b.result()[0])
+    every, _ = exemplars.compute(tally, acts, ds, **kwargs)              # all units
+    assert every.result()[0].shape[0] == 6
+    again, _ = exemplars.compute(tally, acts, ds, **kwargs)              # adopted now
+    assert torch.equal(every.result()[0], again.result()[0])
