@@ -948,6 +948,8 @@ static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
   return 0;
 }
 
+int launch_chain3(const ChainArgs& a, hipStream_t s);   // chain3.hip: the role ping-pong (round 5)
+
 static int launch_chainw(const ChainArgs& a, hipStream_t s) {
   constexpr int lds = 160 * 1024;
   auto kern = a.prof ? chainw_kernel<true> : chainw_kernel<false>;
@@ -977,7 +979,11 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
   static const bool one_wave = getenv("MILAN_CHAIN_WIDE_ONEWAVE") != nullptr;
   if (a.P == 256 && a.prof && one_wave) r = launch_chain_cfg<256, 4, true, 0, false, true>(a, s);
   else if (a.P == 256 && one_wave) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
-  else if (a.P == 256) r = launch_chainw(a, s);
+  else if (a.P == 256) {
+    // MILAN_CHAIN3=0: the round-4 lockstep two-wave form (A/B timing; same bits)
+    static const bool lockstep = getenv("MILAN_CHAIN3") && atoi(getenv("MILAN_CHAIN3")) == 0;
+    r = lockstep ? launch_chainw(a, s) : launch_chain3(a, s);
+  }
   else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);
   // the 128-channel reduce conv runs on the single-accumulator kernel when unfused
   else if (NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128>(a, s);

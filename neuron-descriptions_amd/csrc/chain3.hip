@@ -1,0 +1,534 @@
+// Layer3's expand -> reduce chain (planes 256) as a ROLE ping-pong of the two waves of a SIMD
+// (round 5; replaces the lockstep two-wave form of round 4, which only reached parity).
+//
+// torchvision's Bottleneck (reference call site src/milan/encoders.py:298) ends with
+//     x' = relu(bn3(conv3(t2)) + x)        1x1, 256 -> 1024 channels
+// and the next block starts with
+//     t1' = relu(bn1(conv1(x')))           1x1, 1024 -> 256 channels.
+// One launch does both for 128 pixels per workgroup: x' is written once (residual path,
+// pyramid tap) and reaches the reduce product on chip -- 10 KB of HBM traffic per pixel
+// instead of 14.
+//
+// What sank the earlier forms: every wave did the same thing at the same time,
+// so the MFMA phases of the two waves of a SIMD ran one after the other and the epilogue
+// (HBM round trips, LDS transposes) ran with the matrix pipe idle.  Here the two waves
+// (p, 0) and (p, 1) of SIMD p share pixel block p (32 pixels) but have different JOBS, half
+// a slab apart, so that in every slot exactly one of them multiplies:
+//
+//   wave E = (p, 0): holds the t2 fragments of its 32 pixels for the whole K = 256 (128
+//            registers).  Slot 2s: E(s) = the 64-channel slab s of the expand product, 96
+//            MFMAs, one accumulator per tile, k ascending -- the bits of the unfused kernel.
+//            Slot 2s+1: epilogue of channels 0..31 of slab s (scale, + bias, + residual,
+//            ReLU, split -> HBM and -> the block's LDS strip).
+//   wave R = (p, 1): holds the reduce accumulators 32 px x 256 channels (128 registers).
+//            Slot 2s+2: epilogue of channels 32..63 of slab s (the raw tile came through
+//            the strip).  Slot 2s+3: R(s) = acc1 += W1[:, slab s] . x'[slab s], 96 MFMAs,
+//            x' fragments from the strip.
+//
+//   slot      0      1       2       3       4       5    ...
+//   E-wave  E(0)  epiA(0)  E(1)  epiA(1)  E(2)  epiA(2)
+//   R-wave   --     --    epiB(0)  R(0)  epiB(1)  R(1)
+//
+// A slot is two half-slots of one weight-tile PAIR each (2 x 16 KB, 48 MFMAs per multiplying
+// wave); one s_barrier per half-slot.  Weights stream L2 -> LDS through a ring of three
+// pairs (96 KB); the pair of half-slot q + 2 is issued at the top of half-slot q by the four
+// waves that are NOT multiplying (8 x 1 KB buffer_load ... lds each: no vector ALU, no
+// registers).  The strips are double buffered by slab parity (2 x 4 x 8 KB): x'(s) is read
+// by R(s) while epiA(s + 1) rewrites the other buffer.  LDS = 64 + 96 = all 160 KB.
+// HBM traffic per slot and CU: 16 KB of residual loads (issued one slab ahead, 16 registers
+// per wave) + 16 KB of x' stores against ~3100 cycles of MFMA = 10.3 B/clk -- the chip's HBM
+// share: the kernel is balanced between the two roofs instead of serialising them.
+//
+// Arithmetic: k order, the (hl, lh, hh) order of the three f16 products and every rounding of
+// the epilogue are those of igemm_split16_pp32_kernel + run_epilogue, so X and T1 are bitwise
+// the two separate launches (tools/bench/chainbench.hip, tests/test_gpu_chain.py).
+#include "common.h"
+
+#include <cstdlib>
+
+namespace milan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+__device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// 16 bytes from (uniform base) + (per-lane byte offset); inline asm: the compiler neither
+// sees the pending load nor drains the weight stream in front of its first use -- the
+// counted waits below cover it
+__device__ __forceinline__ f32x4 asm_load16(const float* base, unsigned off) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+  return v;
+}
+__device__ __forceinline__ float clamp_relu(float u) {  // min(max(u, 0), 65504)
+  float r;
+  asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(u), "v"(65504.f));
+  return r;
+}
+// 8 values already clamped to [0, 65504] -> (hi, lo) f16x8 pair (the roundings of split8_rne)
+__device__ __forceinline__ void split8_clamped(const float* x, f32x4* hi_out, f32x4* lo_out) {
+  f32x4 hi, lo;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    hi[d] = cvt_pk_f16(x[2 * d], x[2 * d + 1]);
+    lo[d] = cvt_pk_f16(mix_sub_f16<0>(x[2 * d], hi[d]), mix_sub_f16<1>(x[2 * d + 1], hi[d]));
+  }
+  *hi_out = hi;
+  *lo_out = lo;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+constexpr int kTileFloats = 64 * 64;   // one weight tile: 64 rows x 64 k (16 KB)
+constexpr int kStripFloats = 32 * 64;  // one pixel block's strip: 32 px x 64 channels (8 KB)
+
+}  // namespace
+
+template <bool PROF>
+__global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
+  // in-kernel phase profile (ChainArgs::prof): cycles of wave 0 (E) / wave 4 (R) in
+  // 0 prologue, 1 DMA issue, 2 MFMA half-slots, 3 raw tile -> strip, 4 epilogue items,
+  // 5 counted wait + barrier, 6 residual prefetch, 7 final epilogue
+  long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0;
+  auto stamp = [&](int k) {
+    if constexpr (PROF) {
+      const long long t = __builtin_readcyclecounter();
+      tprof[k] += t - tlast;
+      tlast = t;
+    }
+  };
+  if constexpr (PROF) tlast = __builtin_readcyclecounter();
+  constexpr int P = 256, N3 = 1024, N1 = 256, NSLAB = 16;
+  constexpr int NPAIR = 4 * (NSLAB + 1);  // weight-tile pairs = half-slots
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = wave & 3, h = wave >> 2;   // pixel block = SIMD; role 0 = E, 1 = R
+  const int px = lane & 31, half = lane >> 5;
+  float* strips = smem;                         // [2 buffers][4 blocks][8 KB]
+  float* ring = smem + 2 * 4 * kStripFloats;    // [3 pairs][2 tiles][16 KB]
+  float* strip0 = strips + p * kStripFloats;    // this block's strip, buffer 0 (+32 KB: buffer 1)
+  float sat = 0.f;                              // (common.h: saturation of the split clamp is loud)
+
+  const long wg_m0 = (long)blockIdx.x * 128;
+  const long m0 = wg_m0 + p * 32;               // pixel block's first pixel
+  const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
+
+  // ---- weight-pair DMA ----------------------------------------------------------------
+  // A pair = two 16 KB tiles (64 weight rows x 64 k, 256-byte LDS rows, 16-byte chunk c of
+  // row r at position c ^ (r & 15)).  A wave of the issuing group moves pieces i = 0..3 of
+  // BOTH tiles: rows 16 i + 4 p + (lane >> 4) -- (row & 15) is the same for the four, so one
+  // per-lane offset per matrix serves all of them and the rest of the address is scalar.
+  const int lrow = lane >> 4, lpos = lane & 15;
+  const int wrow = 4 * p + lrow;
+  const unsigned voff3 = (unsigned)((wrow * P + ((lpos ^ wrow) << 2)) * 4);
+  const unsigned voff1 = (unsigned)((wrow * N3 + ((lpos ^ wrow) << 2)) * 4);
+  const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.W3), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.W1), 0, 0x7fffffff, 0x00020000);
+  // pair q: q >> 2 = step s, q & 3 = c; c < 2: W3 rows 64 s.., k tiles 2 c, 2 c + 1;
+  // c >= 2: W1 rows 64 (2 (c - 2) + j).., k = slab s - 1.  Pairs nobody multiplies (R(-1),
+  // E(16), past the end) re-read a valid tile: constant VMEM counts per half-slot.
+  auto issue_pair = [&](int q) {
+    q = q < NPAIR ? q : NPAIR - 1;
+    const int s = q >> 2, c = q & 3;
+    float* dst = ring + ((q % 3) * 2) * kTileFloats + p * 256;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (c < 2) {
+        const int sl = s < NSLAB ? s : NSLAB - 1;
+        const int soff = ((64 * sl) * P + 64 * (2 * c + j)) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srd3, (LDS_AS void*)(dst + j * kTileFloats + i * 1024),
+                                                   16, voff3, soff + i * (16 * P * 4), 0, 0);
+      } else {
+        const int sl = s < 1 ? 0 : s - 1;
+        const int soff = ((64 * (2 * (c - 2) + j)) * N3 + 64 * sl) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srd1, (LDS_AS void*)(dst + j * kTileFloats + i * 1024),
+                                                   16, voff1, soff + i * (16 * N3 * 4), 0, 0);
+      }
+    }
+  };
+
+  // ---- epilogue roles: this wave's half = channels 32 h .. 32 h + 31 of a slab; a lane
+  // takes one 8-channel group (32 bytes of split format) of rows erow and 16 + erow
+  const int erow = lane >> 2, eg = lane & 3;
+  const int G = 4 * h + eg;                      // group within the 64-channel slab
+  unsigned eoff[2];                              // byte offsets of its two rows in X / R
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    long r = p * 32 + 16 * it + erow;
+    r = wg_m0 + r < g.M ? r : (long)g.M - 1 - wg_m0;   // (tail: clamped, stores masked)
+    eoff[it] = (unsigned)((r * N3 + 8 * G) * 4);
+  }
+  const float* rbase = g.R + wg_m0 * N3;
+  float* xbase = g.X + wg_m0 * N3;
+  f32x4 res[2][2], bias3v[2];
+  auto load_res = [&](int j) {                   // residual rows + bias of slab j: 6 loads
+    j = j < NSLAB ? j : NSLAB - 1;
+    bias3v[0] = asm_load16(g.bias3 + 64 * j, (unsigned)(G * 32));
+    bias3v[1] = asm_load16(g.bias3 + 64 * j + 4, (unsigned)(G * 32));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      res[it][0] = asm_load16(rbase + 64 * j, eoff[it]);
+      res[it][1] = asm_load16(rbase + 64 * j + 4, eoff[it]);
+    }
+  };
+  auto res_landed = [&]() {
+    asm volatile("" : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1]),
+                      "+v"(bias3v[0]), "+v"(bias3v[1]));
+  };
+
+  // ---- LDS addresses (bytes), loop-invariant, no vector ALU in the MFMA phases -----------
+  const int fsw = px & 15;
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto lds_addr = [](const float* q) { return (unsigned)(uintptr_t)(LDS_AS const float*)q; };
+  // fa[2 s4 + e]: this lane's (hi | lo = e) chunk of k-step s4 inside a 32 x 64 block with
+  // 256-byte rows -- the x' fragments in the strip, and (+ tile base) the weight fragments
+  unsigned fa[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    fa[k] = (unsigned)((px * 64 + (((4 * (k >> 1) + 2 * half + (k & 1)) ^ fsw) << 2)) * 4);
+  const unsigned strip_b = lds_addr(strip0);
+  const unsigned ring_b = lds_addr(ring);
+  f32x4 wf[2][4];   // [buffer][hi t0, lo t0, hi t1, lo t1]
+  f32x4 xf[2][2];   // [buffer][hi, lo]: x' fragment of the same k-step (reduce)
+  unsigned wa[8];
+  auto set_tile = [&](int q, int j) {   // fragment addresses of tile j of pair q
+    int soff = (int)ring_b + ((q % 3) * 2 + j) * (kTileFloats * 4);
+    asm volatile("" : "+s"(soff));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wa[k] = fa[k] + (unsigned)soff;
+  };
+  auto rd_w = [&](int buf, int s4) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
+  };
+  auto wait_w = [&](int buf, bool last) {
+    if (last)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(4)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
+  };
+  unsigned xa[8];
+  auto set_strip = [&](int buf) {
+    int soff = (int)strip_b + buf * (4 * kStripFloats * 4);
+    asm volatile("" : "+s"(soff));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xa[k] = fa[k] + (unsigned)soff;
+  };
+  auto rd_x = [&](int buf, int s4) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][0]) : "v"(xa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][1]) : "v"(xa[2 * s4 + 1]) : "memory");
+  };
+  auto wait_wx = [&](int buf, bool last) {   // six reads per k-step in the reduce phase
+    if (last)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(6)"
+                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
+                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
+  };
+  // accumulator tile t (32 channels) of a slab -> the strip, channel-per-register to
+  // row-major: row = pixel, fp32 chunk 8 t + 2 qd + half, swizzled by the row
+  auto to_strip = [&](float* st, const f32x16& a, int t) {
+    const int sw = opaque(fsw);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      f32x4 v = {a[4 * qd], a[4 * qd + 1], a[4 * qd + 2], a[4 * qd + 3]};
+      *reinterpret_cast<f32x4*>(st + px * 64 + (((8 * t + 2 * qd + half) ^ sw) << 2)) = v;
+    }
+  };
+  auto row_chunk = [&](float* st, int row, int c) -> float* {
+    return st + row * 64 + ((c ^ opaque(row & 15)) << 2);
+  };
+  // one epilogue item: row 16 it + erow of slab `slab`, this lane's group: raw accumulators
+  // from the strip (+ bias + residual, ReLU, split) -> HBM and -> the strip (x' fragments)
+  auto epi_item = [&](float* st, int it, int slab) {
+    const int row = 16 * it + erow;
+    float* sp0 = row_chunk(st, row, 2 * G);
+    float* sp1 = row_chunk(st, row, 2 * G + 1);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp0);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp1);
+    float v[8];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      v[2 * d] = clamp_relu(v0[2 * d] + bias3v[0][2 * d] + mix_add_f16<0>(res[it][0][d], res[it][1][d]));
+      v[2 * d + 1] = clamp_relu(v0[2 * d + 1] + bias3v[0][2 * d + 1] + mix_add_f16<1>(res[it][0][d], res[it][1][d]));
+      v[4 + 2 * d] = clamp_relu(v1[2 * d] + bias3v[1][2 * d] + mix_add_f16<0>(res[it][0][2 + d], res[it][1][2 + d]));
+      v[5 + 2 * d] = clamp_relu(v1[2 * d + 1] + bias3v[1][2 * d + 1] + mix_add_f16<1>(res[it][0][2 + d], res[it][1][2 + d]));
+    }
+    sat = sat_fold8(v, sat);
+    f32x4 ehi, elo;
+    split8_clamped(v, &ehi, &elo);
+    if (m0 + row < g.M) {
+      float* xp = xbase + 64 * slab + (eoff[it] >> 2);
+      *reinterpret_cast<f32x4*>(xp) = ehi;
+      *reinterpret_cast<f32x4*>(xp + 4) = elo;
+    }
+    *reinterpret_cast<f32x4*>(sp0) = ehi;
+    *reinterpret_cast<f32x4*>(sp1) = elo;
+  };
+  auto end_half = [&]() {   // LDS writes / reads of this half-slot done, then the barrier
+    wait_lgkm0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (h == 0) {
+    // =============================== E-wave ===============================================
+    f32x4 t2h[16], t2l[16];
+    {
+      const float* tp = g.T2 + mfrag * P + half * 8;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        t2h[s] = *reinterpret_cast<const f32x4*>(tp + s * 16);
+        t2l[s] = *reinterpret_cast<const f32x4*>(tp + s * 16 + 4);
+      }
+    }
+    load_res(0);
+    wait_vmcnt<0>();
+    res_landed();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(t2h[s]), "+v"(t2l[s]));
+    __builtin_amdgcn_s_barrier();   // pairs 0 and 1 (issued by the R-waves) have landed
+    stamp(0);
+    for (int s = 0; s <= NSLAB; ++s) {
+      float* st = strip0 + (s & 1) * (4 * kStripFloats);
+      f32x16 acc3[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
+      // ---- half-slots 4 s, 4 s + 1: E(s), k-steps 0..7 and 8..15 --------------------------
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int q = 4 * s + hh;
+        if (s < NSLAB) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            set_tile(q, j);
+            rd_w(0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const int ks = 8 * hh + 4 * j + s4, b = s4 & 1;
+              if (s4 < 3) rd_w(b ^ 1, s4 + 1);
+              wait_w(b, s4 == 3);
+              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
+              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
+              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        stamp(2);
+        if (hh == 1 && s < NSLAB) {
+          // channels 32..63 of the slab go to the R-wave through the strip
+          acc3[1] = acc3[1] * g.scale3;
+          to_strip(st, acc3[1], 1);
+          stamp(3);
+        }
+        // own pieces of pair q + 1 (issued at the top of half-slot 4 s - 1): only the six
+        // residual / bias loads behind them may still fly
+        if (hh == 0) wait_vmcnt<6>();
+        end_half();
+        stamp(5);
+      }
+      // ---- half-slots 4 s + 2, 4 s + 3: weights for E(s + 1); epilogue of channels 0..31 ----
+      issue_pair(4 * s + 4);
+      stamp(1);
+      if (s < NSLAB) {
+        acc3[0] = acc3[0] * g.scale3;
+        to_strip(st, acc3[0], 0);
+        stamp(3);
+        wait_vmcnt<8>();    // the residual / bias of slab s (issued before the 8 pieces)
+        res_landed();
+        epi_item(st, 0, s);
+        stamp(4);
+      }
+      end_half();
+      stamp(5);
+      issue_pair(4 * s + 5);
+      stamp(1);
+      if (s < NSLAB) {
+        epi_item(st, 1, s);
+        stamp(4);
+      }
+      load_res(s + 1);
+      stamp(6);
+      // pair 4 s + 4 (top of the previous half-slot): 8 pieces + 6 loads behind it
+      wait_vmcnt<14>();
+      end_half();
+      stamp(5);
+    }
+  } else {
+    // =============================== R-wave ===============================================
+    f32x16 acc1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[u][r] = 0.f;
+    load_res(0);
+    issue_pair(0);
+    issue_pair(1);
+    wait_vmcnt<0>();
+    res_landed();
+    __builtin_amdgcn_s_barrier();
+    stamp(0);
+    for (int s = 0; s <= NSLAB; ++s) {
+      // slab s - 1 lives in strip buffer (s - 1) & 1
+      float* st = strip0 + ((s + 1) & 1) * (4 * kStripFloats);
+      // ---- half-slots 4 s, 4 s + 1: weights for R(s - 1); epilogue of channels 32..63 -------
+      issue_pair(4 * s + 2);
+      stamp(1);
+      if (s >= 1) {
+        wait_vmcnt<8>();
+        res_landed();
+        epi_item(st, 0, s - 1);
+        stamp(4);
+      }
+      end_half();
+      stamp(5);
+      issue_pair(4 * s + 3);
+      stamp(1);
+      if (s >= 1) {
+        epi_item(st, 1, s - 1);
+        stamp(4);
+      }
+      load_res(s);
+      stamp(6);
+      wait_vmcnt<14>();
+      end_half();
+      stamp(5);
+      // ---- half-slots 4 s + 2, 4 s + 3: R(s - 1), output rows 0..127 and 128..255 ------------
+      set_strip((s + 1) & 1);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int q = 4 * s + 2 + hh;
+        if (s >= 1) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int u0 = 2 * (2 * hh + j);
+            set_tile(q, j);
+            rd_x(0, 0);
+            rd_w(0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const int b = s4 & 1;
+              if (s4 < 3) { rd_x(b ^ 1, s4 + 1); rd_w(b ^ 1, s4 + 1); }
+              wait_wx(b, s4 == 3);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        stamp(2);
+        if (hh == 0) wait_vmcnt<6>();   // own pieces of pair 4 s + 3
+        end_half();
+        stamp(5);
+      }
+    }
+    // ---- the reduce accumulators leave through LDS: tiles 0..3 -> the block's two strips
+    // (the E-wave's half of the final epilogue), tiles 4..7 -> 16 KB of the idle ring
+    wait_vmcnt<0>();
+    res_landed();   // (the last, clamped prefetch has landed: its registers may die now)
+    __builtin_amdgcn_s_barrier();   // every wave is done with strips and ring
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc1[u] = acc1[u] * g.scale1;
+      float* dst = u < 4 ? strip0 + (u >> 1) * (4 * kStripFloats)
+                         : ring + p * (2 * kStripFloats) + ((u - 4) >> 1) * kStripFloats;
+      to_strip(dst, acc1[u], u & 1);
+    }
+  }
+  if (h == 0) {
+    wait_vmcnt<0>();
+    res_landed();
+    __builtin_amdgcn_s_barrier();
+  }
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+
+  // ---- reduce epilogue: t1' = relu(acc1 * scale + bias) in split form; the E-wave takes
+  // channels 0..127 (the strips), the R-wave 128..255 (the ring) -----------------------------
+  {
+    const int frow = lane >> 3, fcol8 = lane & 7;   // 8 lanes cover the 64 channels of a row
+#pragma unroll
+    for (int cidx = 0; cidx < 2; ++cidx) {
+      float* fst = h == 0 ? strip0 + cidx * (4 * kStripFloats)
+                          : ring + p * (2 * kStripFloats) + cidx * kStripFloats;
+      const int n = 128 * h + 64 * cidx + fcol8 * 8;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + n);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + n + 4);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 8 + frow;
+        const long m = m0 + row;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8 + 1));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = clamp_relu(v0[e] + b0[e]);
+          v[4 + e] = clamp_relu(v1[e] + b1[e]);
+        }
+        sat = sat_fold8(v, sat);
+        f32x4 hi, lo;
+        split8_clamped(v, &hi, &lo);
+        if (m < g.M) {
+          float* tp = g.T1 + m * N1 + n;
+          *reinterpret_cast<f32x4*>(tp) = hi;
+          *reinterpret_cast<f32x4*>(tp + 4) = lo;
+        }
+      }
+    }
+  }
+  report_saturation(g.status, sat);
+  if constexpr (PROF) {
+    stamp(7);
+    if (lane == 0 && (wave == 0 || wave == 4) && g.prof)
+      for (int k = 0; k < 8; ++k) g.prof[((long)blockIdx.x * 2 + h) * 8 + k] = tprof[k];
+  }
+}
+
+int launch_chain3(const ChainArgs& a, hipStream_t s) {
+  constexpr int lds = 160 * 1024;
+  auto kern = a.prof ? chain3_kernel<true> : chain3_kernel<false>;
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), lds));
+  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(512), lds, s, a);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace milan

@@ -54,9 +54,12 @@ def test_topk_state_dict_is_netdissect_format(tmp_path, units, k, filled):
                 stub.cov_nearest = stub.corr_nearest = None
                 sys.modules[name] = stub
         sys.path.insert(0, str(REFERENCE))
+        # (the reference tree is read-only: no __pycache__ directories in it)
+        bytecode, sys.dont_write_bytecode = sys.dont_write_bytecode, True
         try:
             from src.deps.netdissect import runningstats
         finally:
+            sys.dont_write_bytecode = bytecode
             sys.path.remove(str(REFERENCE))
         ref = runningstats.RunningTopK(state=loaded)
         got_values, got_index = ref.result()

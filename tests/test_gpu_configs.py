@@ -13,7 +13,7 @@ k = 15, 224x224, F = 3904, H = 512, V = 5004, length 15, split_f16 precision
   config 5  65 536 neurons = a 1.2k-unit set replicated: one rank's shard
             (8192 neurons), beam 50
 Each config is checked (i) by size-independent properties at full N and (ii)
-against the CPU oracle on a fixed 8-neuron subset (near-tie excuses counted,
+against the CPU oracle on a fixed 32-neuron subset (near-tie excuses counted,
 at most one).  The 2-rank bench run (gloo ranks sharing the one GPU) checks the
 sharded path end to end against the 1-rank run.
 """
@@ -34,7 +34,7 @@ from oracle import milan_oracle as O
 pytestmark = pytest.mark.gpu
 
 NV, K, SIZE, LENGTH, LAMBDA = 5000, 15, 224, 15, 0.2
-SUBSET = 8
+SUBSET = 32
 TIE = 1e-3
 REPO = pathlib.Path(__file__).resolve().parent.parent
 
@@ -96,11 +96,11 @@ def write_dataset(root, images, masks, layer_sizes):
 
 
 def subset_indices(n, group=16):
-    """Fixed 8-neuron subset: four neurons of the first batch-of-16 and four of
-    the last (so the CPU oracle only has to run two batches)."""
+    """Fixed 32-neuron subset (was 8): the whole first batch-of-16
+    and the whole last one -- the CPU oracle has to run those two batches anyway."""
     last = ((n - 1) // group) * group
-    tail = [last + j for j in (0, 3, 7, 15) if last + j < n]
-    return [0, 5, 10, 15][:SUBSET - len(tail)] + tail
+    tail = [last + j for j in range(group) if last + j < n and last + j >= group]
+    return list(range(min(group, n)))[:SUBSET - len(tail)] + tail
 
 
 def oracle_subset(images, masks, sd, idx, strategy, beam, group):
@@ -382,3 +382,36 @@ def test_bench_gpus_2_without_torchrun_launches_its_own_ranks():
     assert line['n_gpus'] == 2 and len(line['per_rank']['neurons']) == 2
     assert line['steps'] == 2 and line['value'] > 0
     assert line['scaling'] in ('weak', 'strong')
+
+
+def test_bench_gpus_8_strong_mode_is_the_scale_command(world):
+    """the exact shape of the SCALE command -- `bench.py --gpus 8
+    --neurons-total N` launched WITHOUT torchrun -- as eight gloo ranks sharing this
+    box's one GPU: rc 0, one JSON line, n_gpus 8, and the gathered tokens equal the
+    1-rank run's bit for bit (shards are batch-aligned, kernels are chosen from the layer
+    shape only)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR',
+                        'MASTER_PORT', 'MILAN_DIST_BACKEND')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    hip.release_workspaces()  # the children share this GPU
+    common = ['--neurons-total', '512', '--chunk', '64', '--warmup', '0',
+              '--cpu-sample', '0', '--also-f32-steps', '0', '--no-profile',
+              '--from-host-steps', '0', '--other-configs', '0', '--live-traffic', '0',
+              '--beam', '16']
+    lines = {}
+    for gpus in (8, 1):
+        out = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus',
+                              str(gpus)] + common, capture_output=True, text=True,
+                             env=env, cwd=str(REPO), timeout=1500)
+        assert out.returncode == 0, out.stderr[-3000:]
+        js = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+        assert len(js) == 1, out.stdout[-2000:]
+        lines[gpus] = json.loads(js[0])
+    eight, one = lines[8], lines[1]
+    assert eight['n_gpus'] == 8 and len(eight['per_rank']['neurons']) == 8
+    assert eight['scaling'] == 'strong' and eight['config']['neurons_total'] == 512
+    assert eight['ranks_per_gpu'] == 8 and eight['dist_backend'] == 'gloo'
+    assert eight['status_flags'] == 0 and one['status_flags'] == 0
+    assert (eight['config']['gathered_tokens_sha256'] ==
+            one['config']['gathered_tokens_sha256'])

@@ -63,7 +63,9 @@ int main(int argc, char** argv) {
     long long* pr; CK(hipMalloc((void**)&pr, nwg * 128)); CK(hipMemset(pr, 0, nwg * 128));
     c.prof = pr; launch_chain(c, 0); CK(hipDeviceSynchronize()); c.prof = nullptr;
     std::vector<long long> h(nwg * 16); CK(hipMemcpy(h.data(), pr, nwg * 128, hipMemcpyDeviceToHost));
-    const char* nm[8] = {"prologue", "dma issue", "expand mfma", "hand-over/strip", "reduce mfma", "wait+barrier", "epilogue B", "final epilogue"};
+    // chain3_kernel's counters (MILAN_CHAIN3=0: chainw_kernel's -- prologue, dma issue, expand
+    // mfma, hand-over / strip, reduce mfma, wait + barrier, epilogue B, final epilogue)
+    const char* nm[8] = {"prologue", "dma issue", "mfma half-slots", "raw tile->strip", "epilogue items", "wait+barrier", "residual prefetch", "final epilogue"};
     for (int w = 0; w < 2; ++w) {
       double sum[8] = {0}; for (long i = 0; i < nwg; ++i) for (int k = 0; k < 8; ++k) sum[k] += h[(i * 2 + w) * 8 + k];
       double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
