@@ -45,6 +45,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace milan {
 
@@ -97,8 +98,10 @@ constexpr int kStripFloats = 32 * 64;  // one pixel block's strip: 32 px x 64 ch
 template <bool PROF>
 __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
   // in-kernel phase profile (ChainArgs::prof): cycles of wave 0 (E) / wave 4 (R) in
-  // 0 prologue, 1 DMA issue, 2 MFMA half-slots, 3 raw tile -> strip, 4 epilogue items,
-  // 5 counted wait + barrier, 6 residual prefetch, 7 final epilogue
+  // 0 prologue, 2 busy part of its MFMA half-slots, 4 busy part of its epilogue half-slots
+  // (DMA issue, items, prefetch), 5 / 6 waiting at the barrier that ends an MFMA / epilogue
+  // half-slot, 7 final epilogue.  Stamps sit only where the wave has drained its LDS
+  // counter anyway (s_memtime returns through lgkmcnt), so they do not distort the phases.
   long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
   auto stamp = [&](int k) {
@@ -210,17 +213,25 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
   f32x4 wf[2][4];   // [buffer][hi t0, lo t0, hi t1, lo t1]
   f32x4 xf[2][2];   // [buffer][hi, lo]: x' fragment of the same k-step (reduce)
   unsigned wa[8];
-  auto set_tile = [&](int q, int j) {   // fragment addresses of tile j of pair q
-    int soff = (int)ring_b + ((q % 3) * 2 + j) * (kTileFloats * 4);
+  auto set_pair = [&](int q) {   // fragment addresses of tile 0 of pair q
+    int soff = (int)ring_b + ((q % 3) * 2) * (kTileFloats * 4);
     asm volatile("" : "+s"(soff));
 #pragma unroll
     for (int k = 0; k < 8; ++k) wa[k] = fa[k] + (unsigned)soff;
   };
-  auto rd_w = [&](int buf, int s4) {
+  // weight fragments of k-step s4 of tile 0 / tile 1 of the current pair (wa[] points at tile
+  // 0; tile 1 is +16 KB and the second 32-row MFMA tile +8 KB: immediates)
+  auto rd_w0 = [&](int buf, int s4) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
     asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
     asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
     asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
+  };
+  auto rd_w1 = [&](int buf, int s4) {
+    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
   };
   auto wait_w = [&](int buf, bool last) {
     if (last)
@@ -264,21 +275,27 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
   auto row_chunk = [&](float* st, int row, int c) -> float* {
     return st + row * 64 + ((c ^ opaque(row & 15)) << 2);
   };
-  // one epilogue item: row 16 it + erow of slab `slab`, this lane's group: raw accumulators
-  // from the strip (+ bias + residual, ReLU, split) -> HBM and -> the strip (x' fragments)
-  auto epi_item = [&](float* st, int it, int slab) {
+  // One epilogue item = row 16 it + erow of a slab, this lane's 8-channel group, in two
+  // steps so that the weight DMA of the half-slot is issued while the raw values travel:
+  // epi_read -- the raw accumulators from the strip; epi_finish -- (* scale, + bias, +
+  // residual, ReLU, split) -> HBM and -> the strip (x' fragments of the reduce product).
+  // (__fmul_rn: the scale is rounded on its own, as where the unfused kernel applies it.)
+  auto epi_read = [&](float* st, int it, f32x4* v0, f32x4* v1) {
+    const int row = 16 * it + erow;
+    *v0 = *reinterpret_cast<const f32x4*>(row_chunk(st, row, 2 * G));
+    *v1 = *reinterpret_cast<const f32x4*>(row_chunk(st, row, 2 * G + 1));
+  };
+  auto epi_finish = [&](float* st, int it, int slab, f32x4 v0, f32x4 v1) {
     const int row = 16 * it + erow;
     float* sp0 = row_chunk(st, row, 2 * G);
     float* sp1 = row_chunk(st, row, 2 * G + 1);
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp0);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp1);
     float v[8];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      v[2 * d] = clamp_relu(v0[2 * d] + bias3v[0][2 * d] + mix_add_f16<0>(res[it][0][d], res[it][1][d]));
-      v[2 * d + 1] = clamp_relu(v0[2 * d + 1] + bias3v[0][2 * d + 1] + mix_add_f16<1>(res[it][0][d], res[it][1][d]));
-      v[4 + 2 * d] = clamp_relu(v1[2 * d] + bias3v[1][2 * d] + mix_add_f16<0>(res[it][0][2 + d], res[it][1][2 + d]));
-      v[5 + 2 * d] = clamp_relu(v1[2 * d + 1] + bias3v[1][2 * d + 1] + mix_add_f16<1>(res[it][0][2 + d], res[it][1][2 + d]));
+      v[2 * d] = clamp_relu(__fmul_rn(v0[2 * d], g.scale3) + bias3v[0][2 * d] + mix_add_f16<0>(res[it][0][d], res[it][1][d]));
+      v[2 * d + 1] = clamp_relu(__fmul_rn(v0[2 * d + 1], g.scale3) + bias3v[0][2 * d + 1] + mix_add_f16<1>(res[it][0][d], res[it][1][d]));
+      v[4 + 2 * d] = clamp_relu(__fmul_rn(v1[2 * d], g.scale3) + bias3v[1][2 * d] + mix_add_f16<0>(res[it][0][2 + d], res[it][1][2 + d]));
+      v[5 + 2 * d] = clamp_relu(__fmul_rn(v1[2 * d + 1], g.scale3) + bias3v[1][2 * d + 1] + mix_add_f16<1>(res[it][0][2 + d], res[it][1][2 + d]));
     }
     sat = sat_fold8(v, sat);
     f32x4 ehi, elo;
@@ -291,11 +308,14 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
     *reinterpret_cast<f32x4*>(sp0) = ehi;
     *reinterpret_cast<f32x4*>(sp1) = elo;
   };
-  auto end_half = [&]() {   // LDS writes / reads of this half-slot done, then the barrier
+  // LDS writes / reads of this half-slot done, then the barrier (kind: 2 MFMA, 4 epilogue)
+  auto end_half = [&](int kind) {
     wait_lgkm0();
+    stamp(kind);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    stamp(kind == 2 ? 5 : 6);
   };
 
   if (h == 0) {
@@ -328,64 +348,55 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
       for (int hh = 0; hh < 2; ++hh) {
         const int q = 4 * s + hh;
         if (s < NSLAB) {
+          // eight k-steps (two tiles) in one software pipeline: the fragments of step i + 1
+          // are requested before step i multiplies
+          set_pair(q);
+          rd_w0(0, 0);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            set_tile(q, j);
-            rd_w(0, 0);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-              const int ks = 8 * hh + 4 * j + s4, b = s4 & 1;
-              if (s4 < 3) rd_w(b ^ 1, s4 + 1);
-              wait_w(b, s4 == 3);
-              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
-              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
-              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
-              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
-              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
-              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+          for (int i = 0; i < 8; ++i) {
+            const int ks = 8 * hh + i, b = i & 1;
+            if (i < 3) rd_w0(b ^ 1, i + 1);
+            else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
+            wait_w(b, i == 7);
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
-        }
-        stamp(2);
-        if (hh == 1 && s < NSLAB) {
-          // channels 32..63 of the slab go to the R-wave through the strip
-          acc3[1] = acc3[1] * g.scale3;
-          to_strip(st, acc3[1], 1);
-          stamp(3);
         }
         // own pieces of pair q + 1 (issued at the top of half-slot 4 s - 1): only the six
         // residual / bias loads behind them may still fly
         if (hh == 0) wait_vmcnt<6>();
-        end_half();
-        stamp(5);
+        end_half(2);
       }
       // ---- half-slots 4 s + 2, 4 s + 3: weights for E(s + 1); epilogue of channels 0..31 ----
-      issue_pair(4 * s + 4);
-      stamp(1);
+      // (the raw tiles leave the registers here, not inside the MFMA half-slots; channels
+      // 32..63 go to the R-wave through the strip: its epilogue runs two half-slots later)
+      f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
       if (s < NSLAB) {
-        acc3[0] = acc3[0] * g.scale3;
         to_strip(st, acc3[0], 0);
-        stamp(3);
+        epi_read(st, 0, &r0, &r1);
+      }
+      issue_pair(4 * s + 4);
+      if (s < NSLAB) {
         wait_vmcnt<8>();    // the residual / bias of slab s (issued before the 8 pieces)
         res_landed();
-        epi_item(st, 0, s);
-        stamp(4);
+        epi_finish(st, 0, s, r0, r1);
       }
-      end_half();
-      stamp(5);
-      issue_pair(4 * s + 5);
-      stamp(1);
+      end_half(4);
       if (s < NSLAB) {
-        epi_item(st, 1, s);
-        stamp(4);
+        to_strip(st, acc3[1], 1);
+        epi_read(st, 1, &r0, &r1);
       }
+      issue_pair(4 * s + 5);
+      if (s < NSLAB) epi_finish(st, 1, s, r0, r1);
       load_res(s + 1);
-      stamp(6);
       // pair 4 s + 4 (top of the previous half-slot): 8 pieces + 6 loads behind it
       wait_vmcnt<14>();
-      end_half();
-      stamp(5);
+      end_half(4);
     }
   } else {
     // =============================== R-wave ===============================================
@@ -405,58 +416,48 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
       // slab s - 1 lives in strip buffer (s - 1) & 1
       float* st = strip0 + ((s + 1) & 1) * (4 * kStripFloats);
       // ---- half-slots 4 s, 4 s + 1: weights for R(s - 1); epilogue of channels 32..63 -------
+      f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+      if (s >= 1) epi_read(st, 0, &r0, &r1);
       issue_pair(4 * s + 2);
-      stamp(1);
       if (s >= 1) {
         wait_vmcnt<8>();
         res_landed();
-        epi_item(st, 0, s - 1);
-        stamp(4);
+        epi_finish(st, 0, s - 1, r0, r1);
       }
-      end_half();
-      stamp(5);
+      end_half(4);
+      if (s >= 1) epi_read(st, 1, &r0, &r1);
       issue_pair(4 * s + 3);
-      stamp(1);
-      if (s >= 1) {
-        epi_item(st, 1, s - 1);
-        stamp(4);
-      }
+      if (s >= 1) epi_finish(st, 1, s - 1, r0, r1);
       load_res(s);
-      stamp(6);
       wait_vmcnt<14>();
-      end_half();
-      stamp(5);
+      end_half(4);
       // ---- half-slots 4 s + 2, 4 s + 3: R(s - 1), output rows 0..127 and 128..255 ------------
       set_strip((s + 1) & 1);
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int q = 4 * s + 2 + hh;
         if (s >= 1) {
+          set_pair(q);
+          rd_x(0, 0);
+          rd_w0(0, 0);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int u0 = 2 * (2 * hh + j);
-            set_tile(q, j);
-            rd_x(0, 0);
-            rd_w(0, 0);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-              const int b = s4 & 1;
-              if (s4 < 3) { rd_x(b ^ 1, s4 + 1); rd_w(b ^ 1, s4 + 1); }
-              wait_wx(b, s4 == 3);
-              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
-              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
-              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
-              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+          for (int i = 0; i < 8; ++i) {
+            const int b = i & 1, u0 = 2 * (2 * hh + (i >> 2));
+            if (i < 7) rd_x(b ^ 1, (i + 1) & 3);
+            if (i < 3) rd_w0(b ^ 1, i + 1);
+            else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
+            wait_wx(b, i == 7);
+            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
+            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
+            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
-        stamp(2);
         if (hh == 0) wait_vmcnt<6>();   // own pieces of pair 4 s + 3
-        end_half();
-        stamp(5);
+        end_half(2);
       }
     }
     // ---- the reduce accumulators leave through LDS: tiles 0..3 -> the block's two strips
