@@ -341,7 +341,7 @@ def measure_traffic_live(args):
             q = ('select kernel_name, count(*), sum(value) from counters_collection '
                  'where counter_name = ? group by kernel_name')
             for name, launches, total in db.execute(q, (counter,)):
-                if any(k in name for k in ('igemm', 'chain_kernel', 'stem_fused', 'conv3_p64')):
+                if any(k in name for k in ('igemm', 'chain_kernel', 'chain3_kernel', 'stem_fused', 'conv3_p64')):
                     totals.setdefault(name, {})[counter] = (launches, total)
     best = None
     for name, t in totals.items():

@@ -247,11 +247,10 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
  *   MILAN_FUSE_CONV3  the 64 -> 64 channel 3x3 convolutions of layer1 as a persistent
  *                     kernel with register-resident weights and an LDS-resident input
  *                     tile (csrc/conv3.hip) instead of the implicit GEMM.
- * Default: MILAN_FUSE_CHAIN | MILAN_FUSE_STEM | MILAN_FUSE_CONV3 (environment MILAN_CHAIN=<flags>
- * overrides at context creation). */
+ * Default: all four (environment MILAN_CHAIN=<flags> overrides at context creation). */
 enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
-       MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): two waves per SIMD, at parity with the
-                                      two launches; off by default */
+       MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): the role ping-pong of csrc/chain3.hip
+                                      (round 5) */
        MILAN_FUSE_STEM = 4,
        MILAN_FUSE_CONV3 = 8 };     /* layer1's 3x3 convs: weights in registers (csrc/conv3.hip) */
 int milan_set_fusion(milan_ctx* ctx, int flags);

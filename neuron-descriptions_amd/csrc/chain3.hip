@@ -96,7 +96,7 @@ constexpr int kStripFloats = 32 * 64;  // one pixel block's strip: 32 px x 64 ch
 }  // namespace
 
 template <bool PROF>
-__global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
+__global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles) {
   // in-kernel phase profile (ChainArgs::prof): cycles of wave 0 (E) / wave 4 (R) in
   // 0 prologue, 2 busy part of its MFMA half-slots, 4 busy part of its epilogue half-slots
   // (DMA issue, items, prefetch), 5 / 6 waiting at the barrier that ends an MFMA / epilogue
@@ -125,33 +125,41 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
   float* strip0 = strips + p * kStripFloats;    // this block's strip, buffer 0 (+32 KB: buffer 1)
   float sat = 0.f;                              // (common.h: saturation of the split clamp is loud)
 
-  const long wg_m0 = (long)blockIdx.x * 128;
-  const long m0 = wg_m0 + p * 32;               // pixel block's first pixel
-  const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
+  // Persistent workgroups: tile = 128 pixels, tiles blockIdx.x, + gridDim.x, ...  The weight
+  // stream, the residual prefetch and the t2 fragments of the NEXT tile are requested while
+  // the current one finishes; `qbase` = pairs issued by earlier tiles (mod 3: the ring phase).
+  int tile = blockIdx.x;
+  int qbase = 0;
 
   // ---- weight-pair DMA ----------------------------------------------------------------
   // A pair = two 16 KB tiles (64 weight rows x 64 k, 256-byte LDS rows, 16-byte chunk c of
   // row r at position c ^ (r & 15)).  A wave of the issuing group moves pieces i = 0..3 of
   // BOTH tiles: rows 16 i + 4 p + (lane >> 4) -- (row & 15) is the same for the four, so one
   // per-lane offset per matrix serves all of them and the rest of the address is scalar.
-  const int lrow = lane >> 4, lpos = lane & 15;
-  const int wrow = 4 * p + lrow;
-  const unsigned voff3 = (unsigned)((wrow * P + ((lpos ^ wrow) << 2)) * 4);
-  const unsigned voff1 = (unsigned)((wrow * N3 + ((lpos ^ wrow) << 2)) * 4);
+  // (the per-lane offset is recomputed from the lane number at every issue: five VALU
+  // instructions instead of two registers held through the MFMA phases -- the kernel sits at
+  // the 256-register limit, and a spill RELOAD is a scratch load = a full VMEM drain)
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto voff_of = [&](int ld) {
+    const int l = opaque(lane);
+    const int wrow = 4 * p + (l >> 4), lpos = l & 15;
+    return (unsigned)((wrow * ld + ((lpos ^ wrow) << 2)) * 4);
+  };
   const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.W3), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t srd1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.W1), 0, 0x7fffffff, 0x00020000);
   // pair q: q >> 2 = step s, q & 3 = c; c < 2: W3 rows 64 s.., k tiles 2 c, 2 c + 1;
   // c >= 2: W1 rows 64 (2 (c - 2) + j).., k = slab s - 1.  Pairs nobody multiplies (R(-1),
-  // E(16), past the end) re-read a valid tile: constant VMEM counts per half-slot.
+  // E(16)) re-read a valid tile: constant VMEM counts per half-slot.
   auto issue_pair = [&](int q) {
-    q = q < NPAIR ? q : NPAIR - 1;
+    float* dst = ring + (((qbase + q) % 3) * 2) * kTileFloats + p * 256;
+    q = q < NPAIR ? q : q - NPAIR;   // pairs 68, 69 = the next tile's 0, 1 (same weights)
     const int s = q >> 2, c = q & 3;
-    float* dst = ring + ((q % 3) * 2) * kTileFloats + p * 256;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (c < 2) {
+        const unsigned voff3 = voff_of(P);
         const int sl = s < NSLAB ? s : NSLAB - 1;
         const int soff = ((64 * sl) * P + 64 * (2 * c + j)) * 4;
 #pragma unroll
@@ -159,6 +167,7 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(srd3, (LDS_AS void*)(dst + j * kTileFloats + i * 1024),
                                                    16, voff3, soff + i * (16 * P * 4), 0, 0);
       } else {
+        const unsigned voff1 = voff_of(N3);
         const int sl = s < 1 ? 0 : s - 1;
         const int soff = ((64 * (2 * (c - 2) + j)) * N3 + 64 * sl) * 4;
 #pragma unroll
@@ -173,24 +182,41 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
   // takes one 8-channel group (32 bytes of split format) of rows erow and 16 + erow
   const int erow = lane >> 2, eg = lane & 3;
   const int G = 4 * h + eg;                      // group within the 64-channel slab
-  unsigned eoff[2];                              // byte offsets of its two rows in X / R
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    long r = p * 32 + 16 * it + erow;
-    r = wg_m0 + r < g.M ? r : (long)g.M - 1 - wg_m0;   // (tail: clamped, stores masked)
-    eoff[it] = (unsigned)((r * N3 + 8 * G) * 4);
-  }
-  const float* rbase = g.R + wg_m0 * N3;
-  float* xbase = g.X + wg_m0 * N3;
+  // per-tile geometry: first pixel of the tile / of the block (scalars); a lane's epilogue
+  // row `it` of tile t as a byte offset into X / R (tail: clamped to the last valid row,
+  // stores masked) is recomputed where it is used
+  long wg_m0 = 0, m0 = 0;
+  float* xbase = g.X;
+  auto row_off = [&](int t, int it) {
+    const int l = opaque(lane);
+    const long w0 = (long)t * 128;
+    long r = p * 32 + 16 * it + (l >> 2);
+    r = w0 + r < g.M ? r : (long)g.M - 1 - w0;
+    return (unsigned)((r * N3 + 8 * (4 * h + (l & 3))) * 4);
+  };
+  auto set_geometry = [&](int t) {
+    wg_m0 = (long)t * 128;
+    m0 = wg_m0 + p * 32;
+    xbase = g.X + wg_m0 * N3;
+  };
   f32x4 res[2][2], bias3v[2];
-  auto load_res = [&](int j) {                   // residual rows + bias of slab j: 6 loads
+  // bias of slab j (2 loads: an L2 hit, requested at the top of the epilogue half-slot that
+  // uses it) and residual rows of slab j of tile t (4 loads from HBM, requested one slab
+  // ahead and held through the MFMA half-slots in between)
+  auto load_bias = [&](int j) {
+    j = j < 0 ? 0 : (j < NSLAB ? j : NSLAB - 1);
+    const unsigned off = (unsigned)((4 * h + (opaque(lane) & 3)) * 32);
+    bias3v[0] = asm_load16(g.bias3 + 64 * j, off);
+    bias3v[1] = asm_load16(g.bias3 + 64 * j + 4, off);
+  };
+  auto load_rows = [&](int t, int j) {
     j = j < NSLAB ? j : NSLAB - 1;
-    bias3v[0] = asm_load16(g.bias3 + 64 * j, (unsigned)(G * 32));
-    bias3v[1] = asm_load16(g.bias3 + 64 * j + 4, (unsigned)(G * 32));
+    const float* rb = g.R + (long)t * 128 * N3 + 64 * j;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      res[it][0] = asm_load16(rbase + 64 * j, eoff[it]);
-      res[it][1] = asm_load16(rbase + 64 * j + 4, eoff[it]);
+      const unsigned off = row_off(t, it);
+      res[it][0] = asm_load16(rb, off);
+      res[it][1] = asm_load16(rb + 4, off);
     }
   };
   auto res_landed = [&]() {
@@ -200,7 +226,6 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
 
   // ---- LDS addresses (bytes), loop-invariant, no vector ALU in the MFMA phases -----------
   const int fsw = px & 15;
-  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
   auto lds_addr = [](const float* q) { return (unsigned)(uintptr_t)(LDS_AS const float*)q; };
   // fa[2 s4 + e]: this lane's (hi | lo = e) chunk of k-step s4 inside a 32 x 64 block with
   // 256-byte rows -- the x' fragments in the strip, and (+ tile base) the weight fragments
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
   f32x4 xf[2][2];   // [buffer][hi, lo]: x' fragment of the same k-step (reduce)
   unsigned wa[8];
   auto set_pair = [&](int q) {   // fragment addresses of tile 0 of pair q
-    int soff = (int)ring_b + ((q % 3) * 2) * (kTileFloats * 4);
+    int soff = (int)ring_b + (((qbase + q) % 3) * 2) * (kTileFloats * 4);
     asm volatile("" : "+s"(soff));
 #pragma unroll
     for (int k = 0; k < 8; ++k) wa[k] = fa[k] + (unsigned)soff;
@@ -301,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
     f32x4 ehi, elo;
     split8_clamped(v, &ehi, &elo);
     if (m0 + row < g.M) {
-      float* xp = xbase + 64 * slab + (eoff[it] >> 2);
+      float* xp = xbase + 64 * slab + (row_off(tile, it) >> 2);
       *reinterpret_cast<f32x4*>(xp) = ehi;
       *reinterpret_cast<f32x4*>(xp + 4) = elo;
     }
@@ -318,86 +343,157 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
     stamp(kind == 2 ? 5 : 6);
   };
 
+  // ---- end of a tile: t1' = relu(acc1 * scale + bias) in split form, 64 channels of the
+  // block's 32 pixels from one strip buffer (row-major: 8 lanes cover a row, 8 rows per pass)
+  auto final_items = [&](float* fst, int n0, f32x4 b0, f32x4 b1) {
+    const int frow = opaque(lane) >> 3, fcol8 = opaque(lane) & 7;
+    const int n = n0 + fcol8 * 8;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = ps * 8 + frow;
+      const long m = m0 + row;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8));
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8 + 1));
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = clamp_relu(v0[e] + b0[e]);
+        v[4 + e] = clamp_relu(v1[e] + b1[e]);
+      }
+      sat = sat_fold8(v, sat);
+      f32x4 hi, lo;
+      split8_clamped(v, &hi, &lo);
+      if (m < g.M) {
+        float* tp = g.T1 + m * N1 + n;
+        *reinterpret_cast<f32x4*>(tp) = hi;
+        *reinterpret_cast<f32x4*>(tp + 4) = lo;
+      }
+    }
+  };
+  auto tile_barrier = [&]() {
+    wait_lgkm0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   if (h == 0) {
     // =============================== E-wave ===============================================
     f32x4 t2h[16], t2l[16];
-    {
-      const float* tp = g.T2 + mfrag * P + half * 8;
+    auto load_t2 = [&](int t) {
+      const long mf = ((long)t * 128 + p * 32 + px < g.M) ? (long)t * 128 + p * 32 + px : (long)g.M - 1;
+      const float* tp = g.T2 + mf * P + half * 8;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         t2h[s] = *reinterpret_cast<const f32x4*>(tp + s * 16);
         t2l[s] = *reinterpret_cast<const f32x4*>(tp + s * 16 + 4);
       }
-    }
-    load_res(0);
+    };
+    set_geometry(tile);
+    load_t2(tile);
+    load_rows(tile, 0);
     wait_vmcnt<0>();
     res_landed();
 #pragma unroll
     for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(t2h[s]), "+v"(t2l[s]));
     __builtin_amdgcn_s_barrier();   // pairs 0 and 1 (issued by the R-waves) have landed
     stamp(0);
-    for (int s = 0; s <= NSLAB; ++s) {
-      float* st = strip0 + (s & 1) * (4 * kStripFloats);
-      f32x16 acc3[2];
+    for (;;) {
+      const bool has_next = tile + (int)gridDim.x < ntiles;
+      const int ntile = has_next ? tile + (int)gridDim.x : tile;
+      for (int s = 0; s <= NSLAB; ++s) {
+        float* st = strip0 + (s & 1) * (4 * kStripFloats);
+        f32x16 acc3[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
-      // ---- half-slots 4 s, 4 s + 1: E(s), k-steps 0..7 and 8..15 --------------------------
+          for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
+        // ---- half-slots 4 s, 4 s + 1: E(s), k-steps 0..7 and 8..15 --------------------------
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int q = 4 * s + hh;
-        if (s < NSLAB) {
-          // eight k-steps (two tiles) in one software pipeline: the fragments of step i + 1
-          // are requested before step i multiplies
-          set_pair(q);
-          rd_w0(0, 0);
+        for (int hh = 0; hh < 2; ++hh) {
+          const int q = 4 * s + hh;
+          if (s < NSLAB) {
+            // eight k-steps (two tiles) in one software pipeline: the fragments of step i + 1
+            // are requested before step i multiplies
+            set_pair(q);
+            rd_w0(0, 0);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int ks = 8 * hh + i, b = i & 1;
-            if (i < 3) rd_w0(b ^ 1, i + 1);
-            else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
-            wait_w(b, i == 7);
-            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
-            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
-            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 8; ++i) {
+              const int ks = 8 * hh + i, b = i & 1;
+              if (i < 3) rd_w0(b ^ 1, i + 1);
+              else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
+              wait_w(b, i == 7);
+              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
+              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
+              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
+              acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
+          // own pieces of pair q + 1 (issued at the top of half-slot 4 s - 1): only the four
+          // residual loads behind them may still fly
+          if (hh == 0) wait_vmcnt<4>();
+          end_half(2);
         }
-        // own pieces of pair q + 1 (issued at the top of half-slot 4 s - 1): only the six
-        // residual / bias loads behind them may still fly
-        if (hh == 0) wait_vmcnt<6>();
-        end_half(2);
+        // ---- half-slots 4 s + 2, 4 s + 3: weights for E(s + 1); epilogue of channels 0..31 ----
+        // (the raw tiles leave the registers here, not inside the MFMA half-slots; channels
+        // 32..63 go to the R-wave through the strip: its epilogue runs two half-slots later)
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        // (an inline-asm load's destination must stay live until it lands: no load is
+        // issued whose result nothing will read -- the allocator would reuse the registers)
+        if (s < NSLAB) {
+          load_bias(s);
+          to_strip(st, acc3[0], 0);
+          epi_read(st, 0, &r0, &r1);
+        }
+        issue_pair(4 * s + 4);
+        if (s < NSLAB) {
+          wait_vmcnt<8>();    // the residual / bias of slab s (issued before the 8 pieces)
+          res_landed();
+          epi_finish(st, 0, s, r0, r1);
+        }
+        end_half(4);
+        if (s < NSLAB) {
+          to_strip(st, acc3[1], 1);
+          epi_read(st, 1, &r0, &r1);
+        }
+        issue_pair(4 * s + 5);
+        if (s < NSLAB) epi_finish(st, 1, s, r0, r1);
+        if (s < NSLAB) load_rows(tile, s + 1);
+        else load_rows(ntile, 0);   // the next tile's slab 0
+        // pair 4 s + 4 (top of the previous half-slot): 8 pieces + 4 loads behind it
+        wait_vmcnt<12>();
+        end_half(4);
       }
-      // ---- half-slots 4 s + 2, 4 s + 3: weights for E(s + 1); epilogue of channels 0..31 ----
-      // (the raw tiles leave the registers here, not inside the MFMA half-slots; channels
-      // 32..63 go to the R-wave through the strip: its epilogue runs two half-slots later)
-      f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-      if (s < NSLAB) {
-        to_strip(st, acc3[0], 0);
-        epi_read(st, 0, &r0, &r1);
+      // ---- reduce epilogue, two rounds of 128 channels: the R-wave hands its accumulators
+      // over through the strips (buffer 0: this wave's 64 channels, buffer 1: its own)
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + (lane & 7) * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + (lane & 7) * 8 + 4);
+        tile_barrier();                 // tiles 0..3 are in the strips
+        final_items(strip0, 0, b0, b1);
+        tile_barrier();
       }
-      issue_pair(4 * s + 4);
-      if (s < NSLAB) {
-        wait_vmcnt<8>();    // the residual / bias of slab s (issued before the 8 pieces)
-        res_landed();
-        epi_finish(st, 0, s, r0, r1);
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 + (lane & 7) * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 + (lane & 7) * 8 + 4);
+        tile_barrier();                 // tiles 4..7
+        final_items(strip0, 128, b0, b1);
+        // the next tile's t2 fragments (128 registers: requested only now, so that they are
+        // not live across the items above)
+        if (has_next) load_t2(ntile);
+        tile_barrier();
       }
-      end_half(4);
-      if (s < NSLAB) {
-        to_strip(st, acc3[1], 1);
-        epi_read(st, 1, &r0, &r1);
-      }
-      issue_pair(4 * s + 5);
-      if (s < NSLAB) epi_finish(st, 1, s, r0, r1);
-      load_res(s + 1);
-      // pair 4 s + 4 (top of the previous half-slot): 8 pieces + 6 loads behind it
-      wait_vmcnt<14>();
-      end_half(4);
+      stamp(7);
+      if (!has_next) break;
+      tile = ntile;
+      set_geometry(tile);
+      qbase = (qbase + NPAIR) % 3;
     }
+    wait_vmcnt<0>();
+    res_landed();
   } else {
     // =============================== R-wave ===============================================
     f32x16 acc1[8];
@@ -405,119 +501,104 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g) {
     for (int u = 0; u < 8; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[u][r] = 0.f;
-    load_res(0);
+    set_geometry(tile);
     issue_pair(0);
     issue_pair(1);
     wait_vmcnt<0>();
-    res_landed();
     __builtin_amdgcn_s_barrier();
     stamp(0);
-    for (int s = 0; s <= NSLAB; ++s) {
-      // slab s - 1 lives in strip buffer (s - 1) & 1
-      float* st = strip0 + ((s + 1) & 1) * (4 * kStripFloats);
-      // ---- half-slots 4 s, 4 s + 1: weights for R(s - 1); epilogue of channels 32..63 -------
-      f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-      if (s >= 1) epi_read(st, 0, &r0, &r1);
-      issue_pair(4 * s + 2);
-      if (s >= 1) {
-        wait_vmcnt<8>();
-        res_landed();
-        epi_finish(st, 0, s - 1, r0, r1);
-      }
-      end_half(4);
-      if (s >= 1) epi_read(st, 1, &r0, &r1);
-      issue_pair(4 * s + 3);
-      if (s >= 1) epi_finish(st, 1, s - 1, r0, r1);
-      load_res(s);
-      wait_vmcnt<14>();
-      end_half(4);
-      // ---- half-slots 4 s + 2, 4 s + 3: R(s - 1), output rows 0..127 and 128..255 ------------
-      set_strip((s + 1) & 1);
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int q = 4 * s + 2 + hh;
+    for (;;) {
+      const bool has_next = tile + (int)gridDim.x < ntiles;
+      for (int s = 0; s <= NSLAB; ++s) {
+        // slab s - 1 lives in strip buffer (s - 1) & 1
+        float* st = strip0 + ((s + 1) & 1) * (4 * kStripFloats);
+        // ---- half-slots 4 s, 4 s + 1: weights for R(s - 1); epilogue of channels 32..63 -------
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
         if (s >= 1) {
-          set_pair(q);
-          rd_x(0, 0);
-          rd_w0(0, 0);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int b = i & 1, u0 = 2 * (2 * hh + (i >> 2));
-            if (i < 7) rd_x(b ^ 1, (i + 1) & 3);
-            if (i < 3) rd_w0(b ^ 1, i + 1);
-            else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
-            wait_wx(b, i == 7);
-            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
-            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
-            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
-            acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-            acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          load_bias(s - 1);
+          epi_read(st, 0, &r0, &r1);
         }
-        if (hh == 0) wait_vmcnt<6>();   // own pieces of pair 4 s + 3
-        end_half(2);
-      }
-    }
-    // ---- the reduce accumulators leave through LDS: tiles 0..3 -> the block's two strips
-    // (the E-wave's half of the final epilogue), tiles 4..7 -> 16 KB of the idle ring
-    wait_vmcnt<0>();
-    res_landed();   // (the last, clamped prefetch has landed: its registers may die now)
-    __builtin_amdgcn_s_barrier();   // every wave is done with strips and ring
+        issue_pair(4 * s + 2);
+        if (s >= 1) {
+          wait_vmcnt<8>();
+          res_landed();
+          epi_finish(st, 0, s - 1, r0, r1);
+        }
+        end_half(4);
+        if (s >= 1) epi_read(st, 1, &r0, &r1);
+        issue_pair(4 * s + 3);
+        if (s >= 1) epi_finish(st, 1, s - 1, r0, r1);
+        // pair 4 s + 2 (top of the previous half-slot): 8 pieces (+ 4 residual loads) behind it;
+        // the last step has no slab to prefetch for
+        if (s < NSLAB) {
+          load_rows(tile, s);
+          wait_vmcnt<12>();
+        } else {
+          wait_vmcnt<8>();
+        }
+        end_half(4);
+        // ---- half-slots 4 s + 2, 4 s + 3: R(s - 1), output rows 0..127 and 128..255 ------------
+        set_strip((s + 1) & 1);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      acc1[u] = acc1[u] * g.scale1;
-      float* dst = u < 4 ? strip0 + (u >> 1) * (4 * kStripFloats)
-                         : ring + p * (2 * kStripFloats) + ((u - 4) >> 1) * kStripFloats;
-      to_strip(dst, acc1[u], u & 1);
+        for (int hh = 0; hh < 2; ++hh) {
+          const int q = 4 * s + 2 + hh;
+          if (s >= 1) {
+            set_pair(q);
+            rd_x(0, 0);
+            rd_w0(0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int b = i & 1, u0 = 2 * (2 * hh + (i >> 2));
+              if (i < 7) rd_x(b ^ 1, (i + 1) & 3);
+              if (i < 3) rd_w0(b ^ 1, i + 1);
+              else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
+              wait_wx(b, i == 7);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (hh == 0) {   // own pieces of pair 4 s + 3
+            if (s < NSLAB) wait_vmcnt<4>();
+            else wait_vmcnt<0>();
+          }
+          end_half(2);
+        }
+      }
+      // ---- reduce epilogue: the accumulators leave through the strips, 128 channels per
+      // round (tiles 4 r, 4 r + 1 -> buffer 0 for the E-wave, 4 r + 2, 4 r + 3 -> buffer 1)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 * r + 64 + (lane & 7) * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 * r + 64 + (lane & 7) * 8 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc1[4 * r + k] = acc1[4 * r + k] * g.scale1;
+          to_strip(strip0 + (k >> 1) * (4 * kStripFloats), acc1[4 * r + k], k & 1);
+        }
+        tile_barrier();
+        final_items(strip0 + 4 * kStripFloats, 128 * r + 64, b0, b1);
+        tile_barrier();
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[u][r] = 0.f;
+      stamp(7);
+      if (!has_next) break;
+      tile += (int)gridDim.x;
+      set_geometry(tile);
+      qbase = (qbase + NPAIR) % 3;
     }
-  }
-  if (h == 0) {
     wait_vmcnt<0>();
     res_landed();
-    __builtin_amdgcn_s_barrier();
-  }
-  wait_lgkm0();
-  __builtin_amdgcn_s_barrier();
-
-  // ---- reduce epilogue: t1' = relu(acc1 * scale + bias) in split form; the E-wave takes
-  // channels 0..127 (the strips), the R-wave 128..255 (the ring) -----------------------------
-  {
-    const int frow = lane >> 3, fcol8 = lane & 7;   // 8 lanes cover the 64 channels of a row
-#pragma unroll
-    for (int cidx = 0; cidx < 2; ++cidx) {
-      float* fst = h == 0 ? strip0 + cidx * (4 * kStripFloats)
-                          : ring + p * (2 * kStripFloats) + cidx * kStripFloats;
-      const int n = 128 * h + 64 * cidx + fcol8 * 8;
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + n);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + n + 4);
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 8 + frow;
-        const long m = m0 + row;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8));
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8 + 1));
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = clamp_relu(v0[e] + b0[e]);
-          v[4 + e] = clamp_relu(v1[e] + b1[e]);
-        }
-        sat = sat_fold8(v, sat);
-        f32x4 hi, lo;
-        split8_clamped(v, &hi, &lo);
-        if (m < g.M) {
-          float* tp = g.T1 + m * N1 + n;
-          *reinterpret_cast<f32x4*>(tp) = hi;
-          *reinterpret_cast<f32x4*>(tp + 4) = lo;
-        }
-      }
-    }
   }
   report_saturation(g.status, sat);
   if constexpr (PROF) {
-    stamp(7);
     if (lane == 0 && (wave == 0 || wave == 4) && g.prof)
       for (int k = 0; k < 8; ++k) g.prof[((long)blockIdx.x * 2 + h) * 8 + k] = tprof[k];
   }
@@ -527,7 +608,12 @@ int launch_chain3(const ChainArgs& a, hipStream_t s) {
   constexpr int lds = 160 * 1024;
   auto kern = a.prof ? chain3_kernel<true> : chain3_kernel<false>;
   MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), lds));
-  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(512), lds, s, a);
+  const int ntiles = (a.M + 127) / 128;
+  int cus = 0;
+  MILAN_TRY(device_cus8(&cus));
+  // persistent: one workgroup per CU walks tiles b, b + grid, ...; ChainArgs::prof (timing
+  // experiments) needs 16 counters per workgroup
+  hipLaunchKernelGGL(kern, dim3(ntiles < cus ? ntiles : cus), dim3(512), lds, s, a, ntiles);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }

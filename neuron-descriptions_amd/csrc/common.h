@@ -399,7 +399,7 @@ struct milan_ctx {
   milan_dims d{};
   bool finalized = false;
   int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16
-  int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_STEM | MILAN_FUSE_CONV3;  // milan_set_fusion
+  int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_CHAIN_WIDE | MILAN_FUSE_STEM | MILAN_FUSE_CONV3;  // milan_set_fusion
   // hipGraph cache of whole decode passes (milan_set_graph_capture)
   int graph_capture = 0;
   struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int seen = 0; };

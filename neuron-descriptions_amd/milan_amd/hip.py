@@ -388,8 +388,7 @@ class Context:
                    stem: bool = True, conv3: bool = True) -> None:
         """Cross-layer fusions of the trunk (bitwise-neutral scheduling knob):
         `chain` the expand -> reduce launches of layer1 / layer2, `wide` those of
-        layer3 (default: as `chain` for tests, the library itself starts with
-        chain only), `stem` conv1 + bn1 + ReLU + maxpool as one launch, `conv3` the
+        layer3 (default: as `chain`), `stem` conv1 + bn1 + ReLU + maxpool as one launch, `conv3` the
         register-resident-weight kernel for layer1's 3x3 convolutions."""
         wide = chain if wide is None else wide
         _check(self.lib.milan_set_fusion(

@@ -59,7 +59,9 @@ int main(int argc, char** argv) {
   printf("P=%d M=%ld: X mismatches %ld / %ld, T1 mismatches %ld / %ld\n", P, M, dx, M * N3, dt, M * P);
   if (getenv("CHAIN_PROF")) {
     // chainw_kernel: 8 counters for wave 0 and for wave 4 of every workgroup
-    const long nwg = (M + 127) / 128;
+    // (chain3_kernel is persistent: at most one workgroup per CU; counters are sums over its tiles)
+    const long ntile = (M + 127) / 128;
+    const long nwg = getenv("MILAN_CHAIN3") && atoi(getenv("MILAN_CHAIN3")) == 0 ? ntile : (ntile < 256 ? ntile : 256);
     long long* pr; CK(hipMalloc((void**)&pr, nwg * 128)); CK(hipMemset(pr, 0, nwg * 128));
     c.prof = pr; launch_chain(c, 0); CK(hipDeviceSynchronize()); c.prof = nullptr;
     std::vector<long long> h(nwg * 16); CK(hipMemcpy(h.data(), pr, nwg * 128, hipMemcpyDeviceToHost));
@@ -70,8 +72,8 @@ int main(int argc, char** argv) {
       double sum[8] = {0}; for (long i = 0; i < nwg; ++i) for (int k = 0; k < 8; ++k) sum[k] += h[(i * 2 + w) * 8 + k];
       double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
       printf(" wave %d:", 4 * w);
-      for (int k = 0; k < 8; ++k) printf(" %s %.0f", nm[k], sum[k] / nwg);
-      printf(" | total %.0f cycles/WG\n", tot / nwg);
+      for (int k = 0; k < 8; ++k) printf(" %s %.0f", nm[k], sum[k] / ntile);
+      printf(" | total %.0f cycles per 128-pixel tile\n", tot / ntile);
     }
   }
   if (reps > 1) {
