@@ -200,9 +200,9 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
     xbase = g.X + wg_m0 * N3;
   };
   f32x4 res[2][2], bias3v[2];
-  // bias of slab j (2 loads: an L2 hit, requested at the top of the epilogue half-slot that
-  // uses it) and residual rows of slab j of tile t (4 loads from HBM, requested one slab
-  // ahead and held through the MFMA half-slots in between)
+  // bias of slab j (2 loads) and residual rows of slab j of tile t (4 loads from HBM), both
+  // requested one slab ahead and held through the MFMA half-slots in between (requesting the
+  // bias at the top of the half-slot that uses it cost its L2 round trip every slab)
   auto load_bias = [&](int j) {
     j = j < 0 ? 0 : (j < NSLAB ? j : NSLAB - 1);
     const unsigned off = (unsigned)((4 * h + (opaque(lane) & 3)) * 32);
@@ -345,13 +345,13 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
 
   // ---- end of a tile: t1' = relu(acc1 * scale + bias) in split form, 64 channels of the
   // block's 32 pixels from one strip buffer (row-major: 8 lanes cover a row, 8 rows per pass)
-  auto final_items = [&](float* fst, int n0, f32x4 b0, f32x4 b1) {
+  auto final_items = [&](float* fst, int n0, long bm0, f32x4 b0, f32x4 b1) {
     const int frow = opaque(lane) >> 3, fcol8 = opaque(lane) & 7;
     const int n = n0 + fcol8 * 8;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int row = ps * 8 + frow;
-      const long m = m0 + row;
+      const long m = bm0 + row;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8));
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(row_chunk(fst, row, 2 * fcol8 + 1));
       float v[8];
@@ -370,13 +370,6 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
       }
     }
   };
-  auto tile_barrier = [&]() {
-    wait_lgkm0();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
   if (h == 0) {
     // =============================== E-wave ===============================================
     f32x4 t2h[16], t2l[16];
@@ -392,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
     set_geometry(tile);
     load_t2(tile);
     load_rows(tile, 0);
+    load_bias(0);
     wait_vmcnt<0>();
     res_landed();
 #pragma unroll
@@ -432,9 +426,13 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
               __builtin_amdgcn_sched_barrier(0);
             }
           }
-          // own pieces of pair q + 1 (issued at the top of half-slot 4 s - 1): only the four
-          // residual loads behind them may still fly
-          if (hh == 0) wait_vmcnt<4>();
+          // own pieces of pair q + 1 (issued at the top of half-slot 4 s - 1): only the six
+          // residual / bias loads behind them may still fly
+          if (hh == 0) wait_vmcnt<6>();
+          // the last step has nothing to multiply: the NEXT tile's t2 fragments are requested
+          // here (E(15) was the last reader of the current ones) and travel under the R-wave's
+          // last epilogue / product
+          if (hh == 1 && s == NSLAB && has_next) load_t2(ntile);
           end_half(2);
         }
         // ---- half-slots 4 s + 2, 4 s + 3: weights for E(s + 1); epilogue of channels 0..31 ----
@@ -444,13 +442,17 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
         // (an inline-asm load's destination must stay live until it lands: no load is
         // issued whose result nothing will read -- the allocator would reuse the registers)
         if (s < NSLAB) {
-          load_bias(s);
           to_strip(st, acc3[0], 0);
           epi_read(st, 0, &r0, &r1);
         }
-        issue_pair(4 * s + 4);
+        // weights for E(s + 1): step 15 has no successor in this tile (pairs 64, 65 do not
+        // exist), step 16 requests the next tile's pairs 0, 1
+        const bool feed = s < NSLAB - 1 || (s == NSLAB && has_next);
+        if (feed) issue_pair(4 * s + 4);
         if (s < NSLAB) {
-          wait_vmcnt<8>();    // the residual / bias of slab s (issued before the 8 pieces)
+          // the residual / bias of slab s were requested before the pieces of this half-slot
+          if (feed) wait_vmcnt<8>();
+          else wait_vmcnt<0>();
           res_landed();
           epi_finish(st, 0, s, r0, r1);
         }
@@ -459,41 +461,28 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
           to_strip(st, acc3[1], 1);
           epi_read(st, 1, &r0, &r1);
         }
-        issue_pair(4 * s + 5);
+        if (feed) issue_pair(4 * s + 5);
         if (s < NSLAB) epi_finish(st, 1, s, r0, r1);
-        if (s < NSLAB) load_rows(tile, s + 1);
-        else load_rows(ntile, 0);   // the next tile's slab 0
-        // pair 4 s + 4 (top of the previous half-slot): 8 pieces + 4 loads behind it
-        wait_vmcnt<12>();
+        // (an asm load nobody reads is never issued: the allocator would reuse its registers)
+        if (s < NSLAB - 1) {
+          load_rows(tile, s + 1);
+          load_bias(s + 1);
+        } else if (s == NSLAB && has_next) {   // the next tile's slab 0
+          load_rows(ntile, 0);
+          load_bias(0);
+        }
+        // pair 4 s + 4 (top of the previous half-slot): 8 pieces + 6 loads behind it
+        if (feed) wait_vmcnt<14>();
         end_half(4);
       }
-      // ---- reduce epilogue, two rounds of 128 channels: the R-wave hands its accumulators
-      // over through the strips (buffer 0: this wave's 64 channels, buffer 1: its own)
-      {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + (lane & 7) * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + (lane & 7) * 8 + 4);
-        tile_barrier();                 // tiles 0..3 are in the strips
-        final_items(strip0, 0, b0, b1);
-        tile_barrier();
-      }
-      {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 + (lane & 7) * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 + (lane & 7) * 8 + 4);
-        tile_barrier();                 // tiles 4..7
-        final_items(strip0, 128, b0, b1);
-        // the next tile's t2 fragments (128 registers: requested only now, so that they are
-        // not live across the items above)
-        if (has_next) load_t2(ntile);
-        tile_barrier();
-      }
+      // (the reduce epilogue is the R-wave's: it runs under this wave's first product of the
+      // next tile)
       stamp(7);
       if (!has_next) break;
       tile = ntile;
       set_geometry(tile);
       qbase = (qbase + NPAIR) % 3;
     }
-    wait_vmcnt<0>();
-    res_landed();
   } else {
     // =============================== R-wave ===============================================
     f32x16 acc1[8];
@@ -507,34 +496,63 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     stamp(0);
+    // The reduce epilogue of a tile -- t1' = relu(acc1 * scale + bias) in split form -- runs in
+    // the four half-slots of the NEXT tile's step 0, where this wave has nothing else to do
+    // (no slab behind it yet) and the E-wave multiplies / runs its first epilogue: a quarter
+    // (two accumulator tiles = 64 channels) per half-slot through strip buffer 1 of this block,
+    // which nothing else touches during step 0; same-wave LDS ordering, no extra barrier.
+    // 128 KB of stores per workgroup leave under the next tile's MFMAs instead of after them.
+    bool pending = false;
+    long pm0 = 0;
+    auto final_quarter = [&](int k) {
+      // (gfx9 counts stores in vmcnt: the bias is requested in front of the quarter's stores)
+      const int fcol8 = opaque(lane) & 7;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + 64 * k + fcol8 * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + 64 * k + fcol8 * 8 + 4);
+      float* fst = strip0 + 4 * kStripFloats;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc1[2 * k + t] = acc1[2 * k + t] * g.scale1;
+        to_strip(fst, acc1[2 * k + t], t);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[2 * k + t][e] = 0.f;
+      }
+      final_items(fst, 64 * k, pm0, b0, b1);
+    };
     for (;;) {
       const bool has_next = tile + (int)gridDim.x < ntiles;
       for (int s = 0; s <= NSLAB; ++s) {
         // slab s - 1 lives in strip buffer (s - 1) & 1
         float* st = strip0 + ((s + 1) & 1) * (4 * kStripFloats);
         // ---- half-slots 4 s, 4 s + 1: weights for R(s - 1); epilogue of channels 32..63 -------
+        // (step 0 has no slab behind it: pairs 2, 3 do not exist)
         f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
         if (s >= 1) {
-          load_bias(s - 1);
           epi_read(st, 0, &r0, &r1);
-        }
-        issue_pair(4 * s + 2);
-        if (s >= 1) {
+          issue_pair(4 * s + 2);
           wait_vmcnt<8>();
           res_landed();
           epi_finish(st, 0, s - 1, r0, r1);
+        } else if (pending) {
+          final_quarter(0);
         }
         end_half(4);
-        if (s >= 1) epi_read(st, 1, &r0, &r1);
-        issue_pair(4 * s + 3);
-        if (s >= 1) epi_finish(st, 1, s - 1, r0, r1);
-        // pair 4 s + 2 (top of the previous half-slot): 8 pieces (+ 4 residual loads) behind it;
+        if (s >= 1) {
+          epi_read(st, 1, &r0, &r1);
+          issue_pair(4 * s + 3);
+          epi_finish(st, 1, s - 1, r0, r1);
+        } else if (pending) {
+          final_quarter(1);
+        }
+        // pair 4 s + 2 (top of the previous half-slot): 8 pieces (+ 6 residual / bias loads) behind it;
         // the last step has no slab to prefetch for
         if (s < NSLAB) {
           load_rows(tile, s);
-          wait_vmcnt<12>();
-        } else {
-          wait_vmcnt<8>();
+          load_bias(s);
+        }
+        if (s >= 1) {
+          if (s < NSLAB) wait_vmcnt<14>();
+          else wait_vmcnt<8>();
         }
         end_half(4);
         // ---- half-slots 4 s + 2, 4 s + 3: R(s - 1), output rows 0..127 and 128..255 ------------
@@ -562,40 +580,25 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
               __builtin_amdgcn_sched_barrier(0);
             }
           }
-          if (hh == 0) {   // own pieces of pair 4 s + 3
-            if (s < NSLAB) wait_vmcnt<4>();
+          if (s == 0 && pending) final_quarter(2 + hh);
+          if (hh == 0 && s >= 1) {   // own pieces of pair 4 s + 3
+            if (s < NSLAB) wait_vmcnt<6>();
             else wait_vmcnt<0>();
           }
           end_half(2);
         }
       }
-      // ---- reduce epilogue: the accumulators leave through the strips, 128 channels per
-      // round (tiles 4 r, 4 r + 1 -> buffer 0 for the E-wave, 4 r + 2, 4 r + 3 -> buffer 1)
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 * r + 64 + (lane & 7) * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + 128 * r + 64 + (lane & 7) * 8 + 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          acc1[4 * r + k] = acc1[4 * r + k] * g.scale1;
-          to_strip(strip0 + (k >> 1) * (4 * kStripFloats), acc1[4 * r + k], k & 1);
-        }
-        tile_barrier();
-        final_items(strip0 + 4 * kStripFloats, 128 * r + 64, b0, b1);
-        tile_barrier();
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[u][r] = 0.f;
+      pending = true;
+      pm0 = m0;
       stamp(7);
       if (!has_next) break;
       tile += (int)gridDim.x;
       set_geometry(tile);
       qbase = (qbase + NPAIR) % 3;
     }
-    wait_vmcnt<0>();
-    res_landed();
+    // the last tile's reduce epilogue
+#pragma unroll
+    for (int k = 0; k < 4; ++k) final_quarter(k);
   }
   report_saturation(g.status, sat);
   if constexpr (PROF) {
