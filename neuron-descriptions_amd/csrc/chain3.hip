@@ -236,7 +236,6 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
   const unsigned strip_b = lds_addr(strip0);
   const unsigned ring_b = lds_addr(ring);
   f32x4 wf[2][4];   // [buffer][hi t0, lo t0, hi t1, lo t1]
-  f32x4 xf[2][2];   // [buffer][hi, lo]: x' fragment of the same k-step (reduce)
   unsigned wa[8];
   auto set_pair = [&](int q) {   // fragment addresses of tile 0 of pair q
     int soff = (int)ring_b + (((qbase + q) % 3) * 2) * (kTileFloats * 4);
@@ -266,26 +265,24 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
       asm volatile("s_waitcnt lgkmcnt(4)"
                    : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
   };
-  unsigned xa[8];
-  auto set_strip = [&](int buf) {
+  // x' fragments of a slab (four k-steps x (hi, lo)): read ONCE per slab and kept for its
+  // eight output tiles (re-reading them per tile pair was a third of the reduce phase's LDS
+  // traffic, and the latency of the weight reads rides on that traffic)
+  f32x4 xs[4][2];
+  auto rd_xs = [&](int buf) {
     int soff = (int)strip_b + buf * (4 * kStripFloats * 4);
     asm volatile("" : "+s"(soff));
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xa[k] = fa[k] + (unsigned)soff;
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const unsigned a0 = fa[2 * s4] + (unsigned)soff, a1 = fa[2 * s4 + 1] + (unsigned)soff;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xs[s4][0]) : "v"(a0) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xs[s4][1]) : "v"(a1) : "memory");
+    }
   };
-  auto rd_x = [&](int buf, int s4) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][0]) : "v"(xa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][1]) : "v"(xa[2 * s4 + 1]) : "memory");
-  };
-  auto wait_wx = [&](int buf, bool last) {   // six reads per k-step in the reduce phase
-    if (last)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
-                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(6)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
-                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
+  auto xs_landed = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1]),
+                   "+v"(xs[2][0]), "+v"(xs[2][1]), "+v"(xs[3][0]), "+v"(xs[3][1]) :: "memory");
   };
   // accumulator tile t (32 channels) of a slab -> the strip, channel-per-register to
   // row-major: row = pixel, fp32 chunk 8 t + 2 qd + half, swizzled by the row
@@ -556,27 +553,28 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
         }
         end_half(4);
         // ---- half-slots 4 s + 2, 4 s + 3: R(s - 1), output rows 0..127 and 128..255 ------------
-        set_strip((s + 1) & 1);
+        if (s >= 1) {
+          rd_xs((s + 1) & 1);
+          xs_landed();
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int q = 4 * s + 2 + hh;
           if (s >= 1) {
             set_pair(q);
-            rd_x(0, 0);
             rd_w0(0, 0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              const int b = i & 1, u0 = 2 * (2 * hh + (i >> 2));
-              if (i < 7) rd_x(b ^ 1, (i + 1) & 3);
+              const int b = i & 1, u0 = 2 * (2 * hh + (i >> 2)), k4 = i & 3;
               if (i < 3) rd_w0(b ^ 1, i + 1);
               else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
-              wait_wx(b, i == 7);
-              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
-              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
-              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
-              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
+              wait_w(b, i == 7);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xs[k4][0]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xs[k4][0]), acc1[u0 + 1], 0, 0, 0);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xs[k4][1]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xs[k4][1]), acc1[u0 + 1], 0, 0, 0);
+              acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xs[k4][0]), acc1[u0], 0, 0, 0);
+              acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xs[k4][0]), acc1[u0 + 1], 0, 0, 0);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
