@@ -482,6 +482,11 @@ def main():
                     help='steps of the PCIe-inclusive leg (pinned host uint8 -> '
                     'double-buffered H2D -> describe -> D2H of tokens + scores); '
                     '-1 = as many as the main run, 0 = skip')
+    ap.add_argument('--fast-steps', type=int, default=8,
+                    help='extra timed steps in the FAST mode (layer3 / layer4 on plain f16: '
+                    'narrower than the reference, a reported extra, never `value`), with its '
+                    'caption-flip rate against f32 on --fast-agreement neurons; 0 = skip')
+    ap.add_argument('--fast-agreement', type=int, default=1024)
     ap.add_argument('--precision', default='split_f16',
                     choices=['split_f16', 'f32'],
                     help='split_f16: operands as (hi,lo) f16 pairs, 3 f16 '
@@ -688,6 +693,33 @@ def main():
         hip.profile_enable(False)
         ctx.set_precision(args.precision)
         f32_mode = (e32, ms32, n32)
+
+    # the FAST mode (plain-f16 layer3 / layer4), a reported extra: throughput of the same
+    # steps + what it costs in captions against the exact-fp32 mode
+    fast_mode = None
+    if world == 1 and args.precision != 'f32' and args.fast_steps > 0:
+        ctx.set_precision('f16')
+        step(0)
+        sharding.barrier()
+        torch.cuda.synchronize()
+        hip.profile_enable(True)
+        t5 = time.perf_counter()
+        for i in range(args.fast_steps):
+            step(i)
+        torch.cuda.synchronize()
+        e16 = time.perf_counter() - t5
+        ms16, _, n16 = hip.profile_read()
+        k16 = hip.profile_read_kernels()
+        st16 = hip.profile_read_stages()
+        hip.profile_enable(False)
+        fast_flags = ctx.status(clear=True)
+        ctx.set_precision(args.precision)
+        sys.path.insert(0, str(REPO / 'tools'))
+        import precision_agreement
+        agree = precision_agreement.agreement(ctx, args.fast_agreement, chunk=min(256, args.chunk),
+                                              device=str(device)) \
+            if args.fast_agreement > 0 else None
+        fast_mode = (e16, ms16, n16, k16, st16, fast_flags, agree)
 
     # SURVEY 8(d) configs 1 and 2 on this GPU (same weights, same kernels)
     other = None
@@ -908,6 +940,35 @@ def main():
                 g_alg * 1e9 * n32_neurons / (ms32 * 1e-3) / 1e12 /
                 PEAK_F32_MFMA_TFLOPS,
         }
+    if fast_mode is not None:
+        e16, ms16, n16, k16, st16, fast_flags, agree = fast_mode
+        g_alg = algorithmic_gflop(beam, rerank)
+        n16_neurons = args.fast_steps * args.chunk
+        fk = k16.get('f16', {})
+        result['fast_mode'] = {
+            'note': 'NOT the headline and not a default: layer3 / layer4 of the trunk on plain '
+                    'f16 operands (11 significant bits, 1 MFMA per product, 2-byte '
+                    'activations), everything else split_f16; narrower than the reference',
+            'value': n16_neurons / e16,
+            'unit': 'neuron-descriptions/sec',
+            'steps': args.fast_steps,
+            'speedup_vs_value': n16_neurons / e16 / value,
+            'status_flags': fast_flags,
+            'all_gemm_tflops': g_alg * 1e9 * n16_neurons / (ms16 * 1e-3) / 1e12,
+            # its own kernel against the dense f16 roof (1 MFMA flop per algorithmic flop)
+            'f16_kernel_tflops': fk['flops'] / (fk['ms'] * 1e-3) / 1e12 if fk.get('ms') else None,
+            'f16_kernel_frac_of_f16_peak':
+                fk['flops'] / (fk['ms'] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if fk.get('ms') else None,
+            'f16_kernel_algorithmic_GBs': fk['bytes'] / (fk['ms'] * 1e-3) / 1e9 if fk.get('ms') else None,
+            'stage_ms_per_256': {k: v['region_ms'] / n16_neurons * 256 for k, v in st16.items()
+                                 if v['region_ms'] > 0},
+            # caption-flip rate and score differences against the exact-fp32 mode (and the
+            # same for the bench default, for scale)
+            'agreement_vs_f32': agree,
+        }
+        result['fast_mode_value'] = result['fast_mode']['value']
+        if agree:
+            result['fast_mode_caption_flip_rate'] = agree['f16']['caption_flip_rate']
     # flat copies of the figures a record parser should not have to dig for
     if result.get('pcie_inclusive'):
         result['pcie_inclusive_value'] = result['pcie_inclusive']['value']

@@ -232,7 +232,15 @@ int milan_graph_stats(const milan_ctx* ctx, long long* captures,
  * networks stay in the fp32 error class), while `hi` saturates at 65504 / 2^k (2047).  The
  * scale is invisible at this interface: features, spatial features and descriptions are
  * returned unscaled, and 2^0 reproduces the unscaled storage bit for bit. */
-enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1 };
+enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1,
+       /* "Fast mode" (SURVEY 7 hard part 1): NARROWER than the reference's fp32
+        * -- a reported extra, never the default and never the headline.  layer3 / layer4 of a
+        * bottleneck ResNet trunk run on plain f16 operands (11 significant bits), one f16 MFMA
+        * per product with fp32 accumulation, activations stored as 2 bytes per element;
+        * everything else (stem, layer1 / layer2, decoder, LM) stays MILAN_PRECISION_SPLIT_F16.
+        * Error class 2^-11 of the operand scale; bench.py reports its caption-flip rate against
+        * MILAN_PRECISION_F32 next to its throughput. */
+       MILAN_PRECISION_F16 = 2 };
 
 /* Cross-layer fusions of the trunk (split-f16 mode; results are bitwise those of
  * the unfused schedule, so this is a scheduling knob for A/B timing and tests):
@@ -335,7 +343,8 @@ enum milan_kernel_family {
   MILAN_KERNEL_CHAIN_WIDE = 6,  /* layer3 expand -> reduce chain                         */
   MILAN_KERNEL_STEM = 7,        /* stem_fused_kernel                                     */
   MILAN_KERNEL_CONV3 = 8,       /* conv3_p64_kernel                                      */
-  MILAN_KERNEL_COUNT = 9
+  MILAN_KERNEL_F16 = 9,         /* igemm_f16_pp32_kernel (fast mode)                     */
+  MILAN_KERNEL_COUNT = 10
 };
 int milan_profile_read_kernels(double* table /* [MILAN_KERNEL_COUNT][4] */);
 

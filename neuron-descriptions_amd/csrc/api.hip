@@ -412,8 +412,8 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       const float* residual, float* y, int precision,
                       milan_stream stream) {
   MILAN_REQUIRE(x && weight_oihw && y, MILAN_ERR_ARG, "conv2d: null argument");
-  // precision 2 (test hook only): split-f16 with the LDS-strip 3x3 kernel forced
-  const bool force_strip = precision == 2;
+  // precision 3 (test hook only): split-f16 with the LDS-strip 3x3 kernel forced
+  const bool force_strip = precision == 3;
   if (force_strip) precision = MILAN_PRECISION_SPLIT_F16;
   MILAN_REQUIRE(!force_strip || MILAN_EXPERIMENTS, MILAN_ERR_ARG,
                 "conv2d: the LDS-strip 3x3 kernel is only in an experiments build "
@@ -488,14 +488,18 @@ int milan_set_fusion(milan_ctx* c, int flags) {
 
 int milan_set_precision(milan_ctx* c, int precision) {
   MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
-  MILAN_REQUIRE(precision == MILAN_PRECISION_F32 ||
-                    precision == MILAN_PRECISION_SPLIT_F16,
+  MILAN_REQUIRE(precision == MILAN_PRECISION_F32 || precision == MILAN_PRECISION_SPLIT_F16 ||
+                    precision == MILAN_PRECISION_F16,
                 MILAN_ERR_ARG, "unknown precision mode %d", precision);
-  c->precision = precision;
+  // fast mode = split-f16 everywhere except layer3 / layer4 of a bottleneck trunk
+  c->trunk_f16 = precision == MILAN_PRECISION_F16;
+  c->precision = c->trunk_f16 ? MILAN_PRECISION_SPLIT_F16 : precision;
   return 0;
 }
 
-int milan_get_precision(const milan_ctx* c) { return c ? c->precision : -1; }
+int milan_get_precision(const milan_ctx* c) {
+  return c ? (c->trunk_f16 ? MILAN_PRECISION_F16 : c->precision) : -1;
+}
 
 int milan_profile_enable(int enable) { return gemm_profile_enable(enable); }
 

@@ -109,9 +109,15 @@ struct GemmArgs {
   float* Cs;          // EPI_LSTM: h' once more in split format, or nullptr
   unsigned* status;   // device status word (MILAN_STATUS_* bits) or nullptr; filled by the
                       // launcher from the calling context (set_status_word)
+  int f16;            // fast mode (MILAN_PRECISION_F16): A, W, aux and C hold PLAIN f16 values, 2
+                      // bytes per element.  Every K-side quantity above (Cin, K, Kp, K1, pixel /
+                      // image strides, ldc, ldaux) is then given in 4-byte units, i.e. HALF the
+                      // element count: a row of C f16 channels is addressed exactly like a
+                      // split-format row of C / 2 channels, and the ping-pong kernel multiplies
+                      // "hi . hi + lo . lo" of that pretended row = one f16 MFMA per 16 real k
 };
 
-enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2 };
+enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2, OUT_F16 = 3 };
 
 int launch_gemm(const GemmArgs& g, hipStream_t s);
 // Status word of the context whose entry point is running on this thread (api.hip sets it
@@ -254,6 +260,7 @@ struct ConvW {
   float ws_inv = 1.f;     // exact power of two
   float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
   float* bias_s = nullptr;  // bias x activation scale (split-f16 trunk, see milan_ctx::act_scale)
+  float* wf = nullptr;      // fast mode: the hi halves of `ws` as plain f16 rows [Cout][Kp] (2 B each)
   int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;
   int cin_real = 0;  // channels before padding to a multiple of 4
 };
@@ -398,7 +405,9 @@ struct milan_ctx {
   int device = 0;
   milan_dims d{};
   bool finalized = false;
-  int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16
+  int precision = 0;  // MILAN_PRECISION_F32 / MILAN_PRECISION_SPLIT_F16 (also in fast mode:
+                      // decoder, LM and the front of the trunk stay split)
+  int trunk_f16 = 0;  // MILAN_PRECISION_F16: layer3 / layer4 of a bottleneck trunk on plain f16
   int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_CHAIN_WIDE | MILAN_FUSE_STEM | MILAN_FUSE_CONV3;  // milan_set_fusion
   // hipGraph cache of whole decode passes (milan_set_graph_capture)
   int graph_capture = 0;

@@ -112,6 +112,26 @@ static int scaled_copy(milan_ctx* c, const float* src, int n, float** dst, hipSt
   return 0;
 }
 
+// fast mode: split rows [groups of (hi x8 | lo x8)] -> plain f16 rows (the hi halves);
+// `groups` 32-byte groups in, 16 bytes out each
+__global__ void split_hi_to_f16_kernel(const float* __restrict__ src, long groups,
+                                       float* __restrict__ dst) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < groups;
+       q += (long)gridDim.x * blockDim.x)
+    *reinterpret_cast<v4*>(dst + q * 4) = *reinterpret_cast<const v4*>(src + q * 8);
+}
+static int make_f16_weight(milan_ctx* c, ConvW* w, hipStream_t s) {
+  w->wf = nullptr;
+  if (!w->ws || w->cin % 64 != 0 || w->Kp % 64 != 0 || w->K != w->Kp) return 0;
+  const long groups = (long)w->cout * w->Kp / 8;
+  MILAN_TRY(dev_alloc(c, (void**)&w->wf, sizeof(float) * (size_t)groups * 4));
+  const int blocks = (int)((groups + 255) / 256 < 4096 ? (groups + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split_hi_to_f16_kernel, dim3(blocks), dim3(256), 0, s, w->ws, groups, w->wf);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static int pack_conv(milan_ctx* c, const std::string& conv,
                      const std::string& bn, int stride, int pad, ConvW* out,
                      hipStream_t s, bool split_without_bn = false) {
@@ -163,6 +183,7 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
     MILAN_TRY(make_split_weight(c, out->w, out->cout, out->Kp, &out->ws,
                                 &out->ws_inv, s));
     if (out->ws) MILAN_TRY(scaled_copy(c, out->bias, out->cout, &out->bias_s, s));
+    MILAN_TRY(make_f16_weight(c, out, s));
 #if MILAN_EXPERIMENTS
     if (out->ws && out->kh == 3 && out->kw == 3 && out->Kp == out->K &&
         out->cin % 16 == 0) {
@@ -215,6 +236,7 @@ static int fuse_c3_down(milan_ctx* c, Bottleneck* b, hipStream_t s) {
   MILAN_CHECK_HIP(hipGetLastError());
   MILAN_TRY(make_split_weight(c, f.w, f.cout, f.Kp, &f.ws, &f.ws_inv, s));
   MILAN_TRY(scaled_copy(c, f.bias, f.cout, &f.bias_s, s));
+  MILAN_TRY(make_f16_weight(c, &f, s));
   b->c3d = f;
   return 0;
 }
@@ -466,6 +488,23 @@ __global__ void split_to_f32_kernel(const float* __restrict__ x, long groups,
   }
 }
 
+// split-format groups -> plain f16 (fast mode, at the layer2 -> layer3 boundary):
+// f16(hi + lo), one rounding of the 22-bit value
+__global__ void split_to_f16_kernel(const float* __restrict__ x, long groups,
+                                    float* __restrict__ y) {
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < groups;
+       q += (long)gridDim.x * blockDim.x) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(x + q * 8);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(x + q * 8 + 4);
+    const f16x8_t hh = __builtin_bit_cast(f16x8_t, a);
+    const f16x8_t ll = __builtin_bit_cast(f16x8_t, b);
+    f16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)hh[e] + (float)ll[e]);
+    *reinterpret_cast<f32x4_t*>(y + q * 4) = __builtin_bit_cast(f32x4_t, o);
+  }
+}
+
 // NCHW u8/f32 -> normalised pixel-pair groups in split-f16 format:
 // out[img][y][p] = split8(RGB0 of x=2p-1, RGB0 of x=2p), p in [0, G), zeros
 // outside the image (see pack_stem_pairs_kernel).
@@ -679,7 +718,7 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
 
 // features[img][col_off + c] = sum_p w[p] * tap[img][p][c]   (encoders.py:317)
 // grid (n_images, ceil(C/64)); 4 waves split the pixel list, lane = channel.
-template <bool SPLIT_IN>
+template <int SPLIT_IN>   // 0: fp32 tap, 1: split format, 2: plain f16 (fast mode)
 __global__ __launch_bounds__(256) void masked_pool_kernel(
     const float* __restrict__ tap, int P, int C, int level, Levels lv,
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
@@ -694,10 +733,12 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
   const long base = (long)img * lv.per_image + lv.off[level];
   const int cnt = list_n[img * 5 + level];
   // split format: channel c lives in group c/8 = 32 B [hi x8 | lo x8]
-  const long coff = SPLIT_IN ? (long)(c >> 3) * 8 : c;
-  const float* t = tap + (long)blockIdx.x * P * C + coff;
+  const long coff = SPLIT_IN == 1 ? (long)(c >> 3) * 8 : c;
+  const float* t = tap + (SPLIT_IN == 2 ? (long)blockIdx.x * P * (C / 2) : (long)blockIdx.x * P * C + coff);
   auto fetch = [&](int p) -> float {
-    if constexpr (SPLIT_IN) {
+    if constexpr (SPLIT_IN == 2) {
+      return (float)reinterpret_cast<const _Float16*>(t + (long)p * (C / 2))[c];
+    } else if constexpr (SPLIT_IN == 1) {
       const _Float16* q =
           reinterpret_cast<const _Float16*>(t + (long)p * C) + (c & 7);
       return (float)q[0] + (float)q[8];
@@ -870,6 +911,21 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
   return g;
 }
 
+// fast mode (MILAN_PRECISION_F16): the same conv on plain f16 tensors -- every K-side
+// quantity in 4-byte units (GemmArgs::f16), weights = the f16 rows of ConvW::wf
+static GemmArgs conv_args_f16(const ConvW& cw, const float* in, int n, int H, int W,
+                              float* out, int epi, const float* aux, const float* zero,
+                              int* Ho, int* Wo) {
+  GemmArgs g = conv_args(cw, in, n, H, W, out, epi, aux, zero, Ho, Wo, true);
+  g.W = cw.wf; g.W3 = nullptr;
+  g.f16 = 1; g.out_split = 0; g.aux_split = 0;
+  g.Cin = cw.cin / 2; g.K = cw.K / 2; g.Kp = cw.Kp / 2;
+  g.a_pix_stride = cw.cin / 2;
+  g.a_img_stride = (long)H * W * (cw.cin / 2);
+  g.ldc = cw.cout / 2; g.ldaux = cw.cout / 2;
+  return g;
+}
+
 static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                              const void* masks, int mask_dtype, int n, int H,
                              int W, float* features, Arena& ws, hipStream_t s,
@@ -978,6 +1034,11 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     for (const Bottleneck& b : c->blocks[li])
       split = split && b.c1.ws && b.c2.ws && (b.basic || b.c3.ws) &&
               (!b.has_down || b.down.ws);
+  // fast mode: layer3 / layer4 of a bottleneck trunk on plain f16 (needs every conv's f16 rows)
+  bool fast = split && c->trunk_f16 && !spatial && c->d.trunk_kind == MILAN_TRUNK_BOTTLENECK;
+  for (int li = 2; li < 4 && fast; ++li)
+    for (const Bottleneck& b : c->blocks[li])
+      fast = fast && !b.basic && b.c1.wf && b.c2.wf && (b.has_down ? b.c3d.wf != nullptr : b.c3.wf != nullptr);
   const bool pair_stem = split && c->stem_pair.ws != nullptr;
   const int G = (W + 2) / 2;  // pixel-pair groups per image row
 
@@ -1018,13 +1079,18 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (cnt == 0) return 0;
     StageScope scope(MILAN_STAGE_ENC_POOL, s);
     const int P = pl.lv.h[level] * pl.lv.w[level];
-    if (split && level > 0)
-      hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(cnt, (C + 63) / 64),
+    if (fast && level >= 3)
+      hipLaunchKernelGGL(masked_pool_kernel<2>, dim3(cnt, (C + 63) / 64),
+                         dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
+                         pl.list_w, pl.list_n, features, F, col_off, img0,
+                         1.f / c->act_scale, poison);
+    else if (split && level > 0)
+      hipLaunchKernelGGL(masked_pool_kernel<1>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col_off, img0,
                          1.f / c->act_scale, poison);
     else
-      hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(cnt, (C + 63) / 64),
+      hipLaunchKernelGGL(masked_pool_kernel<0>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col_off, img0, 1.f, poison);
     MILAN_CHECK_HIP(hipGetLastError());
@@ -1107,9 +1173,42 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   for (int li = 0; li < 4; ++li) {
     stage.emplace(MILAN_STAGE_ENC_LAYER1 + li, s);
     const std::vector<Bottleneck>& blocks = c->blocks[li];
+    if (fast && li == 2) {
+      // the residual stream leaves the split format: f16(hi + lo) into the spare buffer
+      const long groups = (long)n * h * w * ((wd * 4) << 1) / 8;   // layer2's output channels
+      const int nb = (int)((groups + 255) / 256 < 16384 ? (groups + 255) / 256 : 16384);
+      hipLaunchKernelGGL(split_to_f16_kernel, dim3(nb), dim3(256), 0, s, x, groups, pl.ds);
+      MILAN_CHECK_HIP(hipGetLastError());
+      y = x; x = pl.ds;
+    }
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
       const Bottleneck& b = blocks[bi];
       int h1, w1, h2, w2, h3, w3;
+      if (fast && li >= 2) {
+        GemmArgs g1 = conv_args_f16(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr, c->zero, &h1, &w1);
+        MILAN_TRY(launch_gemm(g1, s));
+        GemmArgs g2 = conv_args_f16(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU, nullptr, c->zero, &h2, &w2);
+        MILAN_TRY(launch_gemm(g2, s));
+        if (b.has_down) {
+          // c3 and the downsample as ONE GEMM over [t2 | x(strided)]
+          GemmArgs g3 = conv_args_f16(b.c3d, pl.t2, n, h2, w2, y, EPI_BIAS_RELU, nullptr, c->zero, &h3, &w3);
+          g3.Cin = b.c3.cin / 2;
+          g3.a_pix_stride = b.c3.cin / 2;
+          g3.a_img_stride = (long)h2 * w2 * (b.c3.cin / 2);
+          g3.A2 = x; g3.K1 = b.c3.K / 2; g3.H2 = h; g3.W2d = w;
+          g3.stride2 = b.down.stride;
+          g3.a2_pix_stride = b.down.cin / 2;
+          g3.a2_img_stride = (long)h * w * (b.down.cin / 2);
+          g3.flop_k = b.c3.K + b.down.K;
+          MILAN_TRY(launch_gemm(g3, s));
+        } else {
+          GemmArgs g3 = conv_args_f16(b.c3, pl.t2, n, h2, w2, y, EPI_BIAS_RES_RELU, x, c->zero, &h3, &w3);
+          MILAN_TRY(launch_gemm(g3, s));
+        }
+        float* tmp = x; x = y; y = tmp;
+        h = h3; w = w3;
+        continue;
+      }
       if (b.basic) {
         // BasicBlock (resnet18/34): relu(bn2(conv2(relu(bn1(conv1(x))))) + id)
         GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
@@ -1169,7 +1268,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       const Bottleneck* nbp = !last_of_stage ? &blocks[bi + 1]
                               : (li + 1 < 4 && !c->blocks[li + 1].empty())
                                     ? &c->blocks[li + 1][0] : nullptr;
-      if (split && nbp != nullptr &&
+      if (split && nbp != nullptr && !(fast && last_of_stage && li + 1 >= 2) &&
           (c->fusion & (b.c3.cin >= 256 ? MILAN_FUSE_CHAIN_WIDE : MILAN_FUSE_CHAIN))) {
         const Bottleneck& nb = *nbp;
         const int P = b.c3.cin;
@@ -1458,11 +1557,11 @@ static int alexnet_run_batch(milan_ctx* c, const void* images, int image_dtype,
   auto pool = [&](int l, bool tap_split) -> int {
     const int P = pl.lv.h[l] * pl.lv.w[l], C = pl.C[l];
     if (tap_split)
-      hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(n, (C + 63) / 64),
+      hipLaunchKernelGGL(masked_pool_kernel<1>, dim3(n, (C + 63) / 64),
                          dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col, 0, 1.f);
     else
-      hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(n, (C + 63) / 64),
+      hipLaunchKernelGGL(masked_pool_kernel<0>, dim3(n, (C + 63) / 64),
                          dim3(256), 0, s, pl.a[l], P, C, l, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col, 0, 1.f);
     MILAN_CHECK_HIP(hipGetLastError());

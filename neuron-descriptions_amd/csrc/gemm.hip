@@ -294,6 +294,77 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
     report_saturation(g.status, sat);
   };
 
+  // (2b) fast mode: plain f16 out (and aux), 8 channels = 16 bytes per lane
+  auto epilogue_f16 = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    const int col8 = (lane & 7) * 8;
+    const int n = col0 + col8;
+    const bool n_ok = n < g.N;
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n_ok) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + n);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+    constexpr bool RES = EPI == EPI_BIAS_RES_RELU;
+    float sat = 0.f;
+    f32x4 res[RES ? 2 : 1][4];
+    auto load_res = [&](int i, f32x4 (&r)[4]) {   // one row-tile ahead (see epilogue_split8)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = row0 + i * 32 + it * 8 + (lane >> 3);
+        r[it] = (m < g.M && n_ok)
+                    ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g.aux) +
+                                                      ((long)m * g.ldaux * 4 + n * 2))
+                    : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    if constexpr (RES) load_res(0, res[0]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (RES) {
+        if (i + 1 < TM) load_res(i + 1, res[(i + 1) & 1]);
+      }
+      to_stage(i);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int m = row0 + i * 32 + row;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage_out + row * SROW + sw(row, col8));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage_out + row * SROW + sw(row, col8 + 4));
+        if (m < g.M && n_ok) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = v0[e] + bias8[e];
+            v[4 + e] = v1[e] + bias8[4 + e];
+          }
+          if constexpr (RES) {
+            const f16x8v a = __builtin_bit_cast(f16x8v, res[i & 1][it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
+          }
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if constexpr (EPI == EPI_BIAS)
+              asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x[e]) : "v"(v[e]), "v"(-65504.f), "v"(65504.f));
+            else
+              asm("v_med3_f32 %0, %1, 0, %2" : "=v"(x[e]) : "v"(v[e]), "v"(65504.f));
+          }
+          sat = sat_fold8(x, sat);
+          f32x4 o;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) o[d] = cvt_pk_f16(x[2 * d], x[2 * d + 1]);
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(g.C) + ((long)m * g.ldc * 4 + n * 2)) = o;
+        }
+      }
+    }
+    report_saturation(g.status, sat);
+  };
+
   // (4) LSTM cell on gate-interleaved columns: the wave's 64 columns are
   // [i x16 | f x16 | g x16 | o x16] of hidden units col0/4 .. col0/4 + 15; a lane
   // takes the four gates of 4 consecutive units from the staged tile.
@@ -404,6 +475,12 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
   };
   if (g.epilogue == EPI_LSTM) {
     epilogue_lstm();
+  } else if (g.out_mode == OUT_F16) {
+    switch (g.epilogue) {
+      case EPI_BIAS_RELU: epilogue_f16(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
+      case EPI_BIAS_RES_RELU: epilogue_f16(std::integral_constant<int, EPI_BIAS_RES_RELU>{}); break;
+      default: epilogue_f16(std::integral_constant<int, EPI_BIAS>{}); break;
+    }
   } else if (g.out_mode == OUT_SPLIT8) {
     // only the conv epilogues exist in split form
     switch (g.epilogue) {
@@ -1569,7 +1646,7 @@ struct PpLoader {
 // N = 128 layers of layer2 and the odd-width products): wave tiles 64 x 64 (4 x 2 waves), the
 // SAME loader -- W rows 128..255 of a slot carry out-of-range offsets, for which the DMA writes
 // zeros without a fetch -- so every counted wait is the 256-column kernel's.
-template <int BNW>
+template <int BNW, bool F16 = false>
 __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int tid, bool prefetched,
                                                   bool has_next, int ntile_m, int ntile_n) {
   const GemmArgs g = reload_gemm_args();
@@ -1745,6 +1822,24 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   auto multiply = [&]() {
+    if constexpr (F16) {
+      // fast mode: the "hi" and "lo" chunks of a pretended split row are two different k
+      // ranges of a plain f16 row -- hi . hi + lo . lo = one MFMA per 16 real k
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(ah[i]), as_f16x8(bh[j]),
+                                                             acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(al[i]), as_f16x8(bl[j]),
+                                                             acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1918,6 +2013,19 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, 
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   split16_pp32_tile<256>(tile_m, tile_n, tid, false, false, tile_m, tile_n);
+}
+
+// fast mode (GemmArgs::f16): the same tile with one MFMA per 16 real k
+template <int BNW>
+__global__ __launch_bounds__(512, 2) void igemm_f16_pp32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  const int T = tiles_m * tiles_n;
+  const int q = blockIdx.x;
+  if (q >= T) return;
+  const int tile = xcd_tile(q, T);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  split16_pp32_tile<BNW, true>(tile_m, tile_n, tid, false, false, tile_m, tile_n);
 }
 
 __global__ __launch_bounds__(512, 2) void igemm_split16_pp_kernel(GemmArgs g, int tiles_m,
@@ -2293,6 +2401,7 @@ static double gemm_algorithmic_bytes(const GemmArgs& g) {
     c = M * H * (g.Cs ? 3.0 : 2.0);
     aux = M * H;
   }
+  if (g.f16) { c *= 0.5; aux *= 0.5; }   // (2-byte outputs; the K side is already in 4-byte units)
   return 4.0 * (a + (double)g.N * g.Kp + c + aux);
 }
 struct Profiler {
@@ -2483,6 +2592,18 @@ static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
   return 0;
 }
 
+template <int BNW>
+static int launch_f16_pp32(const GemmArgs& g, hipStream_t s) {
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + BNW - 1) / BNW;
+  const size_t lds = size_t(5) * 256 * 32 * sizeof(float);
+  profile_tag_kernel(MILAN_KERNEL_F16);
+  auto kern = igemm_f16_pp32_kernel<BNW>;
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, g, tiles_m, tiles_n);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static int launch_split16_pp(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
   const size_t lds = size_t(4) * (256 + 256) * 16 * sizeof(float);
@@ -2654,6 +2775,19 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
                   MILAN_ERR_SHAPE, "gemm: bad LSTM epilogue geometry (N=%d ldc=%d)",
                   g.N, g.ldc);
     g.out_mode = OUT_VEC4;
+  } else if (g.f16) {
+    // fast mode: plain f16 operands through the ping-pong tile only (K-side quantities in
+    // 4-byte units, see GemmArgs::f16)
+    MILAN_REQUIRE(g.a_split && !g.out_split && !g.aux_split && g.N % 8 == 0 && g.ldc % 4 == 0 &&
+                      aligned16(g.C) && (g.bias == nullptr || aligned16(g.bias)) &&
+                      (g.aux == nullptr || (g.ldaux % 4 == 0 && aligned16(g.aux))) &&
+                      (g.epilogue == EPI_BIAS || g.epilogue == EPI_BIAS_RELU ||
+                       g.epilogue == EPI_BIAS_RES_RELU) &&
+                      g.Cin % 32 == 0 && (!g.A2 || g.K1 % 32 == 0) && g.N >= 128 &&
+                      !g.chunk_major && ((long)g.H + g.pad) < 32768 && ((long)g.Wd + g.pad) < 32768,
+                  MILAN_ERR_SHAPE, "gemm: unsupported fast-mode (f16) layer N=%d Cin=%d epi=%d",
+                  g.N, g.Cin, g.epilogue);
+    g.out_mode = OUT_F16;
   } else if (g.out_split || g.aux_split) {
     MILAN_REQUIRE(g.out_split && g.N % 8 == 0 && g.ldc % 8 == 0 && aligned16(g.C) &&
                       (g.bias == nullptr || aligned16(g.bias)) &&
@@ -2681,6 +2815,11 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
                 MILAN_ERR_SHAPE, "gemm: two-source A needs the split16 kernels");
   if (g.a_split) {
     if (g.acc_scale == 0.f) g.acc_scale = 1.f;
+    if (g.f16) {
+      MILAN_REQUIRE(pp_eligible(g), MILAN_ERR_SHAPE, "gemm: fast-mode layer exceeds the 32-bit "
+                    "buffer offsets of the ping-pong kernel");
+      return g.N % 256 == 0 ? launch_f16_pp32<256>(g, s) : launch_f16_pp32<128>(g, s);
+    }
     if (!cin32) {
       // per-lane taps (8-slot groups): only the narrow-N tile is built for it
       MILAN_REQUIRE(g.Cin % 8 == 0 && g.N <= 64 && !g.A2, MILAN_ERR_SHAPE,

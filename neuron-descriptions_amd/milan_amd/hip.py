@@ -21,15 +21,16 @@ LIB_PATH = pathlib.Path(os.environ.get('MILAN_LIB') or
                        pathlib.Path(__file__).resolve().parent / 'lib' / 'libmilan_hip.so')
 
 GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _RERANK
-PRECISION_F32, PRECISION_SPLIT_F16 = 0, 1
-PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16}
+PRECISION_F32, PRECISION_SPLIT_F16, PRECISION_F16 = 0, 1, 2
+# 'f16' = the fast mode: narrower than the reference's fp32 (include/milan_hip.h), never a default
+PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16, 'f16': PRECISION_F16}
 FUSE_CHAIN, FUSE_CHAIN_WIDE, FUSE_STEM, FUSE_CONV3 = 1, 2, 4, 8  # milan_set_fusion flags (include/milan_hip.h)
 SKETCH_COMPACT, SKETCH_INSERT, SKETCH_MOVE, SKETCH_HALVE = 0, 1, 2, 3
 # milan_status bits (include/milan_hip.h)
 STATUS_SATURATED, STATUS_NONFINITE_INPUT = 1, 2
 # enum milan_kernel_family (milan_profile_read_kernels)
 KERNEL_FAMILIES = ('other', 'pp32_256', 'pp32_128', 'split_other', 'f32', 'chain',
-                   'chain_wide', 'stem', 'conv3')
+                   'chain_wide', 'stem', 'conv3', 'f16')
 
 
 class SketchOp(ctypes.Structure):
@@ -43,7 +44,7 @@ class SketchOp(ctypes.Structure):
 
 DRAW_BIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 # conv2d_nhwc test hook only: split_f16 with the LDS-strip 3x3 kernel forced
-_CONV_PRECISIONS = dict(PRECISIONS, split_f16_strip=2)
+_CONV_PRECISIONS = dict(f32=0, split_f16=1, split_f16_strip=3)
 DTYPE_U8, DTYPE_F32 = 0, 1
 
 ERR_ARG, ERR_SHAPE, ERR_STATE, ERR_WORKSPACE, ERR_NO_LM = -1, -2, -3, -4, -5
