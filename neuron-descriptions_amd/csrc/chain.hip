@@ -26,8 +26,8 @@
 //   t2 fragments of its 32 pixels       P / 2 registers, loaded once
 //   reduce accumulators 32 px x P       P / 2 registers, live for the whole kernel
 //   expand accumulators, one 64-channel slab at a time (32 registers)
-// P = 256 (layer3) needs ~400 registers: one wave per SIMD (4 waves, 128 pixels
-// per workgroup).  Weights stream HBM/L2 -> LDS by global_load_lds_dwordx4 in
+// (P = 256 -- layer3 -- would need ~400 registers per wave: it runs on the role ping-pong
+// of chain3.hip instead.)  Weights stream HBM/L2 -> LDS by global_load_lds_dwordx4 in
 // 16 KB tiles (64 weight rows x 64 k) through a 4-deep ring shared by the waves;
 // a tile is 24 MFMAs per wave.  Per 64-channel slab j of the expand output:
 //   S1  expand:  acc3 = W3[slab j] . t2          (P/64 tiles)
@@ -53,34 +53,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
-
-// 16 bytes from (uniform base) + (per-lane byte offset)
-__device__ __forceinline__ f32x4 asm_load16(const float* base, unsigned off) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
-  return v;
-}
-
-template <int SEL> __device__ __forceinline__ float mix_add(float h, float l) { return mix_add_f16<SEL>(h, l); }
-template <int SEL> __device__ __forceinline__ float mix_sub(float x, float h) { return mix_sub_f16<SEL>(x, h); }
-__device__ __forceinline__ float cvt_pk(float a, float b) { return cvt_pk_f16(a, b); }
-// 8 values already clamped to [0, 65504] -> (hi, lo) f16x8 pair: the roundings of
-// chain_split8 in 12 instructions instead of 32
-__device__ __forceinline__ void split8_fast(const float* x, f32x4* hi_out, f32x4* lo_out) {
-  f32x4 hi, lo;
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    hi[d] = cvt_pk(x[2 * d], x[2 * d + 1]);
-    lo[d] = cvt_pk(mix_sub<0>(x[2 * d], hi[d]), mix_sub<1>(x[2 * d + 1], hi[d]));
-  }
-  *hi_out = hi;
-  *lo_out = lo;
-}
-__device__ __forceinline__ float clamp_relu(float u) {  // min(max(u, 0), 65504)
-  float r;
-  asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(u), "v"(65504.f));
-  return r;
-}
 
 // 8 fp32 <-> (hi, lo) f16x8 pair, hi saturating: common.h
 __device__ inline void chain_split8(const float* v, f32x4* hi_out, f32x4* lo_out) {
@@ -519,414 +491,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   }
 }
 
-// ---- planes 256 (layer3): 128 pixels per workgroup, TWO waves per SIMD --------------
-// The one-wave form above needs ~400 registers for a wave's 32 pixels (t2 fragments 128 +
-// reduce accumulators 128 + ...).  Here the two waves (p, 0) and (p, 1) of a SIMD share
-// pixel block p and halve both big register sets:
-//   expand  K-split: wave (p, 0) holds the t2 fragments of k 0..127, wave (p, 1) those
-//           of k 128..255.  (p, 0) starts slab s from zero over its half and HANDS the
-//           accumulator over through LDS; one step later (p, 1) loads it and finishes
-//           the slab over its half -- one accumulator, k ascending, i.e. the bits of the
-//           unfused kernel -- while (p, 0) is already on slab s + 1;
-//   reduce  channel-split: (p, h) accumulates output channels 128 h .. 128 h + 127.
-// Step s = 0..16, all eight waves in lockstep (one barrier per weight-tile pair):
-//   A  (p,0): E1(slab s) -> hand-over        (p,1): E2(slab s-1) -> raw strip
-//   B  both:  epilogue of slab s-1, 16 rows x 64 channels each (whole 256-byte row
-//             segments): scale, + bias, + residual, ReLU, split -> HBM and -> strip
-//   C  both:  reduce over slab s-1 (x' fragments from the strip) into their 128 channels
-// Weights stream as PAIRS of 16 KB tiles (the tile of the h = 0 waves and the tile of the
-// h = 1 waves; 24 MFMAs per wave per pair) through a ring of three pairs; LDS = ring
-// 96 KB + strips 32 KB (XOR-swizzled, unpadded) + hand-over 32 KB = all 160 KB.
-// Residual / bias loads are issued by inline asm so that the compiler does not drain
-// the weight stream in front of their first use; the counted waits below cover them.
-template <bool PROF>
-__global__ __launch_bounds__(512, 2) void chainw_kernel(ChainArgs g) {
-  // in-kernel phase profile (experiments: ChainArgs::prof): cycles of wave 0 / wave 4 in
-  // 0 prologue, 1 DMA issue, 2 expand MFMAs, 3 hand-over / strip, 4 reduce MFMAs, 5 counted
-  // wait + barrier, 6 epilogue B, 7 final epilogue
-  long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = 0;
-  auto stamp = [&](int k) {
-    if constexpr (PROF) {
-      const long long t = __builtin_readcyclecounter();
-      tprof[k] += t - tlast;
-      tlast = t;
-    }
-  };
-  if constexpr (PROF) tlast = __builtin_readcyclecounter();
-  constexpr int P = 256, N3 = 1024, N1 = 256, NSLAB = 16;
-  constexpr int NIT = 4 * (NSLAB + 1);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p = wave & 3, h = wave >> 2;
-  const int px = lane & 31, half = lane >> 5;
-  float* strip = smem + p * 2048;                       // 32 px x 64 channels (8 KB per block)
-  float* hand = smem + 4 * 2048 + p * 2048;             // hand-over, 8 KB per block
-  float* ring = smem + 8 * 2048;                        // [6][16 KB]
-
-  const long m0 = (long)blockIdx.x * 128 + p * 32;      // pixel block's first pixel
-  const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
-  const bool tail = (long)(blockIdx.x + 1) * 128 > g.M;  // workgroup-uniform
-
-  // ---- weight-pair DMA: this wave moves 4 of the 16 pieces of tile h of the pair ------
-  // piece i of a wave = rows 16 i + 4 (wave & 3) .. + 3 of the tile: the swizzle term
-  // (row & 15) is the same for the four pieces, so ONE per-lane offset per matrix serves
-  // all of them and the rest of the address is scalar (buffer_load ... lds: descriptor +
-  // VGPR offset + SGPR offset; no vector ALU in the issue path)
-  const int lrow = lane >> 4, lpos = lane & 15;
-  const int wrow = 4 * (wave & 3) + lrow;                // row within a 16-row group
-  const unsigned voff3 = (unsigned)((wrow * P + ((lpos ^ wrow) << 2)) * 4);
-  const unsigned voff1 = (unsigned)((wrow * N3 + ((lpos ^ wrow) << 2)) * 4);
-  const __amdgpu_buffer_rsrc_t srd3 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.W3), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srd1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.W1), 0, 0x7fffffff, 0x00020000);
-  auto issue_pair = [&](int q) {
-    q = q < NIT ? q : NIT - 1;
-    const int s = q >> 2, it = q & 3;
-    float* dst = ring + (h * 3 + q % 3) * kTileFloats + (wave & 3) * 256;  // h's three slots
-    if (it < 2) {
-      int sl = h == 0 ? s : s - 1;
-      sl = sl < 0 ? 0 : (sl > NSLAB - 1 ? NSLAB - 1 : sl);
-      const int soff = ((64 * sl) * P + 128 * h + 64 * it) * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd3, (LDS_AS void*)(dst + i * 1024), 16, voff3,
-                                                 soff + i * (16 * P * 4), 0, 0);
-    } else {
-      const int sl = s < 1 ? 0 : s - 1;
-      const int soff = ((128 * h + 64 * (it - 2)) * N3 + 64 * sl) * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd1, (LDS_AS void*)(dst + i * 1024), 16, voff1,
-                                                 soff + i * (16 * N3 * 4), 0, 0);
-    }
-  };
-
-  // ---- prologue --------------------------------------------------------------------
-  f32x4 t2h[8], t2l[8];
-  {
-    const float* tp = g.T2 + mfrag * P + 128 * h + half * 8;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      t2h[s] = *reinterpret_cast<const f32x4*>(tp + s * 16);
-      t2l[s] = *reinterpret_cast<const f32x4*>(tp + s * 16 + 4);
-    }
-  }
-  // row-major epilogue roles: 8 lanes cover the 64 channels of a row, 8 rows per pass;
-  // this wave owns rows 16 h .. 16 h + 15 of the block
-  const int erow = lane >> 3, ecol = (lane & 7) * 8;
-  f32x4 res[2][2], bias3v[2];
-  // per-lane byte offsets of its two epilogue rows within the workgroup's 128 rows of X / R
-  // (clamped to the last valid row in the tail workgroup; stores are masked there)
-  const long wg_m0 = (long)blockIdx.x * 128;
-  unsigned eoff[2];
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    long r = p * 32 + 16 * h + 8 * ps + erow;
-    r = wg_m0 + r < g.M ? r : (long)g.M - 1 - wg_m0;
-    eoff[ps] = (unsigned)((r * N3 + ecol) * 4);
-  }
-  const float* rbase = g.R + wg_m0 * N3;
-  float* xbase = g.X + wg_m0 * N3;
-  auto load_res = [&](int j) {
-    j = j < NSLAB ? j : NSLAB - 1;
-    bias3v[0] = asm_load16(g.bias3 + 64 * j, (unsigned)(ecol * 4));
-    bias3v[1] = asm_load16(g.bias3 + 64 * j + 4, (unsigned)(ecol * 4));
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      res[ps][0] = asm_load16(rbase + 64 * j, eoff[ps]);
-      res[ps][1] = asm_load16(rbase + 64 * j + 4, eoff[ps]);
-    }
-  };
-  load_res(0);
-  issue_pair(0);
-  issue_pair(1);
-
-  f32x16 acc1[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[u][r] = 0.f;
-
-  const int fsw = px & 15;
-  // The swizzled LDS addresses of the strip accesses outside the MFMA phases are
-  // loop-invariant, and there are dozens of them: left to itself the compiler keeps them
-  // all in registers (and spills).  An opaque copy of the swizzle term at each use site
-  // makes it recompute them (one v_xad_u32 per access).
-  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
-  // Fragment reads with NO vector ALU in the MFMA phases (a VALU instruction next to the
-  // partner wave's MFMA stream costs 10-20 cycles: profiles/r4_mainloop_prototype.txt).
-  // fa[2 s4 + e]: LDS address, inside the block's strip, of this lane's (hi | lo = e) chunk
-  // of k-step s4; wa[] = the same inside the wave's weight tile of the current iteration
-  // (eight additions per iteration, before its MFMAs); the second MFMA tile (rows 32..63)
-  // is +8 KB, an immediate.  The reads are inline asm, so the waits are counted here, not
-  // by the compiler.
-  auto lds_addr = [](const float* p) { return (unsigned)(uintptr_t)(LDS_AS const float*)p; };
-  // (fa[] carries the strip's own address: the x' fragments are read at fa[], the weight
-  // fragments at wa[] = fa[] + (tile - strip), a scalar)
-  unsigned fa[8], wa[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    fa[k] = lds_addr(strip) +
-            (unsigned)((px * 64 + (((4 * (k >> 1) + 2 * half + (k & 1)) ^ fsw) << 2)) * 4);
-  const unsigned wbase = lds_addr(ring) + (unsigned)(h * 3) * (kTileFloats * 4) - lds_addr(strip);
-  f32x4 wf[2][4];   // [buffer][hi t0, lo t0, hi t1, lo t1]
-  f32x4 xf[2][2];   // [buffer][hi, lo]: x' fragment of the same k-step (reduce phase)
-  auto rd_x = [&](int buf, int s4) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][0]) : "v"(fa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1" : "=v"(xf[buf][1]) : "v"(fa[2 * s4 + 1]) : "memory");
-  };
-  auto wait_wx = [&](int buf, bool last) {   // six reads per k-step in the reduce phase
-    if (last)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
-                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(6)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]),
-                     "+v"(xf[buf][0]), "+v"(xf[buf][1]) :: "memory");
-  };
-  auto rd_w = [&](int buf, int s4) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
-  };
-  // fragments of `buf` (and everything read before them) have landed; the four reads
-  // issued after them may still fly (LAST: nothing was issued after them)
-  auto wait_w = [&](int buf, bool last) {
-    if (last)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(4)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
-  };
-  // swizzled 32 x 64 strip: row r keeps its 16-byte chunk c at position c ^ (r & 15)
-  auto to_strip = [&](float* st, const f32x16& a, int t) {
-    const int sw = opaque(fsw);
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      f32x4 v = {a[4 * qd], a[4 * qd + 1], a[4 * qd + 2], a[4 * qd + 3]};
-      *reinterpret_cast<f32x4*>(st + px * 64 + (((8 * t + 2 * qd + half) ^ sw) << 2)) = v;
-    }
-  };
-  auto row_chunk = [&](float* st, int row, int c) -> float* {
-    return st + row * 64 + ((c ^ opaque(row & 15)) << 2);
-  };
-
-  wait_vmcnt<4>();   // t2, residual, bias, pair 0 have landed; pair 1 may fly
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(t2h[s]), "+v"(t2l[s]));
-  asm volatile("" : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1]),
-                    "+v"(bias3v[0]), "+v"(bias3v[1]));
-
-  stamp(0);
-  for (int s = 0; s <= NSLAB; ++s) {
-    const bool expand_on = h == 0 ? s < NSLAB : s >= 1;
-    f32x16 acc3[2];
-    // epilogue B's output rows, stored to HBM from inside the next iteration (defined on
-    // every path of the step, so that they are not carried around the loop)
-    f32x4 ehi[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 elo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int q = 4 * s + it;
-      // VMEM of this iteration: the four DMA pieces of pair q + 2 and, in the iteration
-      // after an epilogue, that epilogue's HBM traffic -- the next residual / bias loads
-      // and the four x' stores (kept OUT of B: eighty 1 KB operations issued by eight
-      // waves at once queue for ~1300 cycles at the CU's one address unit).  The h = 0
-      // waves issue ahead of their MFMAs, the h = 1 waves in the middle of theirs.
-      auto vmem = [&]() { issue_pair(q + 2); };
-      if (h == 0) vmem();
-      stamp(1);
-      {
-        int soff = (int)wbase + (q % 3) * (kTileFloats * 4);
-        asm volatile("" : "+s"(soff));   // (eight adds per iteration, not 24 registers)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wa[k] = fa[k] + (unsigned)soff;
-      }
-      bool issued = h == 0;
-      if (it < 2) {
-        // ---- A: this wave's half of the expand product --------------------------------
-        if (it == 0) {
-          // (defined on every path: the accumulator must not be live across B and C)
-          if (h == 0 || !expand_on) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
-          } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(hand + ((4 * t + i) * 64 + lane) * 4);
-                acc3[t][4 * i] = v[0]; acc3[t][4 * i + 1] = v[1];
-                acc3[t][4 * i + 2] = v[2]; acc3[t][4 * i + 3] = v[3];
-              }
-          }
-        }
-        if (expand_on) {
-          rd_w(0, 0);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const int ks = 4 * it + s4, b = s4 & 1;
-            if (s4 < 3) rd_w(b ^ 1, s4 + 1);
-            wait_w(b, s4 == 3);
-            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
-            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
-            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s4 == 1 && h == 1) { vmem(); issued = true; __builtin_amdgcn_sched_barrier(0); }
-          }
-          stamp(2);
-          if (it == 1) {
-            if (h == 0) {
-#pragma unroll
-              for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  const f32x4 v = {acc3[t][4 * i], acc3[t][4 * i + 1], acc3[t][4 * i + 2], acc3[t][4 * i + 3]};
-                  *reinterpret_cast<f32x4*>(hand + ((4 * t + i) * 64 + lane) * 4) = v;
-                }
-            } else {
-#pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                acc3[t] = acc3[t] * g.scale3;
-                to_strip(strip, acc3[t], t);
-              }
-            }
-          }
-        }
-      } else if (s >= 1) {
-        // ---- C: reduce over slab s - 1, output rows 128 h + 64 (it - 2) .. ------------------
-        const int u0 = 2 * (it - 2);
-        rd_x(0, 0);
-        rd_w(0, 0);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int b = s4 & 1;
-          if (s4 < 3) { rd_x(b ^ 1, s4 + 1); rd_w(b ^ 1, s4 + 1); }
-          wait_wx(b, s4 == 3);
-          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
-          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][1]), acc1[u0], 0, 0, 0);
-          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][1]), acc1[u0 + 1], 0, 0, 0);
-          acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xf[b][0]), acc1[u0], 0, 0, 0);
-          acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xf[b][0]), acc1[u0 + 1], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (s4 == 1 && h == 1) { vmem(); issued = true; __builtin_amdgcn_sched_barrier(0); }
-        }
-      }
-      if (!issued) vmem();   // (an iteration without MFMAs for this wave: steps 0 and 16)
-      stamp(it < 2 ? 3 : 4);
-      // Pair q + 1 must have landed.  VMEM ops younger than its pieces: the four pieces
-      // of pair q + 2 -- and, in the iteration after an epilogue, the six loads and four
-      // stores issued with them (stores may retire early: they are not counted on).
-      if (tail) wait_vmcnt<0>();
-      else if (it == 2 && s >= 1 && s < NSLAB) wait_vmcnt<10>();
-      else wait_vmcnt<4>();   // (after the last epilogue: its 4 uncounted stores + 4 pieces)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      stamp(5);
-      if (it == 1 && s >= 1) {
-        // ---- B: epilogue of slab s - 1, rows 16 h .. 16 h + 15 of the block: LDS and ALU
-        // only (the residual / bias registers were loaded one step ago: older than
-        // everything the last counted wait let fly)
-        asm volatile("" : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[1][0]), "+v"(res[1][1]),
-                          "+v"(bias3v[0]), "+v"(bias3v[1]));
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const int row = 16 * h + 8 * ps + erow;
-          float* sp0 = row_chunk(strip, row, 2 * (lane & 7));
-          float* sp1 = row_chunk(strip, row, 2 * (lane & 7) + 1);
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp0);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp1);
-          float v[8];
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            v[2 * d] = clamp_relu(v0[2 * d] + bias3v[0][2 * d] + mix_add<0>(res[ps][0][d], res[ps][1][d]));
-            v[2 * d + 1] = clamp_relu(v0[2 * d + 1] + bias3v[0][2 * d + 1] + mix_add<1>(res[ps][0][d], res[ps][1][d]));
-            v[4 + 2 * d] = clamp_relu(v1[2 * d] + bias3v[1][2 * d] + mix_add<0>(res[ps][0][2 + d], res[ps][1][2 + d]));
-            v[5 + 2 * d] = clamp_relu(v1[2 * d + 1] + bias3v[1][2 * d + 1] + mix_add<1>(res[ps][0][2 + d], res[ps][1][2 + d]));
-          }
-          split8_fast(v, &ehi[ps], &elo[ps]);
-          const long m = m0 + row;
-          if (m < g.M) {
-            float* xp = xbase + 64 * (s - 1) + (eoff[ps] >> 2);
-            *reinterpret_cast<f32x4*>(xp) = ehi[ps];
-            *reinterpret_cast<f32x4*>(xp + 4) = elo[ps];
-          }
-          *reinterpret_cast<f32x4*>(sp0) = ehi[ps];
-          *reinterpret_cast<f32x4*>(sp1) = elo[ps];
-        }
-        // (inline-asm loads: their destination registers must stay live until they land --
-        // after the last epilogue nothing would read them, so none are issued there)
-        if (s < NSLAB) load_res(s);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        stamp(6);
-      }
-    }
-  }
-  wait_vmcnt<0>();  // dummy pairs drained before the ring becomes the staging area
-  __builtin_amdgcn_s_barrier();
-
-  // ---- reduce epilogue: t1' = relu(acc1 * scale + bias) in split form --------------
-  float* fstrip = ring + wave * 2048;
-#pragma unroll
-  for (int cidx = 0; cidx < 2; ++cidx) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      acc1[2 * cidx + t] = acc1[2 * cidx + t] * g.scale1;
-      to_strip(fstrip, acc1[2 * cidx + t], t);
-    }
-    const int n = 128 * h + 64 * cidx + ecol;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias1 + n);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias1 + n + 4);
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int row = ps * 8 + erow;
-      const long m = m0 + row;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row_chunk(fstrip, row, 2 * (lane & 7)));
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(row_chunk(fstrip, row, 2 * (lane & 7) + 1));
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = clamp_relu(v0[e] + b0[e]);
-        v[4 + e] = clamp_relu(v1[e] + b1[e]);
-      }
-      f32x4 hi, lo;
-      split8_fast(v, &hi, &lo);
-      if (m < g.M) {
-        float* tp = g.T1 + m * N1 + n;
-        *reinterpret_cast<f32x4*>(tp) = hi;
-        *reinterpret_cast<f32x4*>(tp + 4) = lo;
-      }
-    }
-  }
-  if constexpr (PROF) {
-    stamp(7);
-    if (lane == 0 && (wave == 0 || wave == 4) && g.prof)
-      for (int k = 0; k < 8; ++k) g.prof[((long)blockIdx.x * 2 + h) * 8 + k] = tprof[k];
-  }
-}
-
-// (Round 3 also built a producer / consumer form for P = 256 -- expand waves holding t2
-// and issuing all DMA, reduce waves running the epilogue and S3 one slab behind, one of
-// each per SIMD.  Bitwise correct, 8.6 ms per layer3 block pair against 7.5 ms for the
-// 4-wave form above and 8.0 ms for the two separate launches: with a barrier per
-// weight tile the reduce wave's epilogue (63 k of 212 k cycles per workgroup) still
-// runs while its partner waits, and both waves' MFMAs share one pipe.  Removed from the
-// library; numbers in DESIGN.md section 5.)
+// Planes 256 (layer3) run on the role ping-pong of chain3.hip (round 5).  Its predecessors
+// lived here and are gone: round 3's one-wave form (t2 fragments + reduce accumulators of 32
+// pixels = ~400 registers, one wave per SIMD: 8.17 ms against 7.27 for the two launches) and a
+// producer / consumer form (8.6 ms); round 4's lockstep two-wave form with a K-split expand
+// and an accumulator hand-over (bitwise, 2.83 against 2.79 ms: parity, because the two waves
+// of a SIMD multiplied one after the other and the epilogue ran with the pipe idle).  Numbers:
+// DESIGN.md section 4.4, profiles/r3_experiments.txt, profiles/r4_experiments.txt E.
 
 bool chain_supported(int P, int KD, int NR) {
   if (NR == 2 * P) return KD == 0 && P == 64;  // stage boundary layer1 -> layer2
@@ -950,15 +521,6 @@ static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
 
 int launch_chain3(const ChainArgs& a, hipStream_t s);   // chain3.hip: the role ping-pong (round 5)
 
-static int launch_chainw(const ChainArgs& a, hipStream_t s) {
-  constexpr int lds = 160 * 1024;
-  auto kern = a.prof ? chainw_kernel<true> : chainw_kernel<false>;
-  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), lds));
-  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(512), lds, s, a);
-  MILAN_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 int launch_chain(const ChainArgs& a0, hipStream_t s) {
   ChainArgs a = a0;
   if (a.status == nullptr) a.status = status_word();
@@ -976,14 +538,7 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
       4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * R1 + 4 * P * (K3 + R1)), s);
   profile_tag_kernel(a.P == 256 ? MILAN_KERNEL_CHAIN_WIDE : MILAN_KERNEL_CHAIN);
   int r;
-  static const bool one_wave = getenv("MILAN_CHAIN_WIDE_ONEWAVE") != nullptr;
-  if (a.P == 256 && a.prof && one_wave) r = launch_chain_cfg<256, 4, true, 0, false, true>(a, s);
-  else if (a.P == 256 && one_wave) r = launch_chain_cfg<256, 4, true, 0, false>(a, s);
-  else if (a.P == 256) {
-    // MILAN_CHAIN3=0: the round-4 lockstep two-wave form (A/B timing; same bits)
-    static const bool lockstep = getenv("MILAN_CHAIN3") && atoi(getenv("MILAN_CHAIN3")) == 0;
-    r = lockstep ? launch_chainw(a, s) : launch_chain3(a, s);
-  }
+  if (a.P == 256) r = launch_chain3(a, s);
   else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);
   // the 128-channel reduce conv runs on the single-accumulator kernel when unfused
   else if (NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128>(a, s);

@@ -552,3 +552,18 @@ def test_shared_gpu_probe_is_quiet_without_a_gpu(recwarn):
     assert hip.other_compute_processes() == []
     hip.warn_if_gpu_is_shared()
     assert not [w for w in recwarn.list if 'compute queues' in str(w.message)]
+
+
+def test_check_isa_pins_the_instruction_streams_of_the_ring_kernels():
+    """VERDICT r4 item 8 / ADVICE r3: the hand-counted `s_waitcnt vmcnt(N)` sites were written
+    against a definite number of VMEM operations per kernel; tools/check_isa.py disassembles
+    the built objects and asserts them (runs in build() and as `make check-isa`)."""
+    import subprocess
+    import sys
+    build = REPO / 'neuron-descriptions_amd' / 'csrc' / 'build'
+    if not (build / 'chain3.o').exists():
+        pytest.skip('library objects not built in this checkout')
+    out = subprocess.run([sys.executable, str(REPO / 'tools' / 'check_isa.py')],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert 'kernels match' in out.stdout
