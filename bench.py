@@ -834,7 +834,7 @@ def main():
         if traffic_bytes is None:
             live_reason, traffic_note = traffic_note, None
     for name in ([] if traffic_bytes is not None else
-                 ['r4_hbm_traffic.json', 'r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.json']):
+                 ['r5_hbm_traffic.json', 'r4_hbm_traffic.json', 'r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.json']):
         tpath = REPO / 'profiles' / name
         if args.precision != 'f32' and tpath.exists():
             with open(tpath) as f:

@@ -60,13 +60,14 @@ namespace {
 
 __device__ inline f16x8 h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-// 16 bytes from (uniform base) + (per-lane byte offset); inline asm: the compiler neither
-// sees the pending load nor drains the weight stream in front of its first use -- the
-// counted waits below cover it
-__device__ __forceinline__ f32x4 asm_load16(const float* base, unsigned off) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
-  return v;
+// 16 bytes from (uniform base) + (per-lane byte offset).  A PLAIN load: the compiler sees it
+// pending and orders every use -- and every copy or spill of its destination -- behind its own
+// counted wait.  (An inline-asm load hides the pending state: the allocator may then move or
+// spill the destination registers before the data has landed.  That passed every test on an
+// idle GPU and corrupted a value now and then once a second process stretched the HBM latency:
+// tests/test_gpu_concurrent.py, profiles/r5_experiments.txt.)
+__device__ __forceinline__ f32x4 load16(const float* base, unsigned off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
 }
 __device__ __forceinline__ float clamp_relu(float u) {  // min(max(u, 0), 65504)
   float r;
@@ -206,8 +207,8 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
   auto load_bias = [&](int j) {
     j = j < 0 ? 0 : (j < NSLAB ? j : NSLAB - 1);
     const unsigned off = (unsigned)((4 * h + (opaque(lane) & 3)) * 32);
-    bias3v[0] = asm_load16(g.bias3 + 64 * j, off);
-    bias3v[1] = asm_load16(g.bias3 + 64 * j + 4, off);
+    bias3v[0] = load16(g.bias3 + 64 * j, off);
+    bias3v[1] = load16(g.bias3 + 64 * j + 4, off);
   };
   auto load_rows = [&](int t, int j) {
     j = j < NSLAB ? j : NSLAB - 1;
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const unsigned off = row_off(t, it);
-      res[it][0] = asm_load16(rb, off);
-      res[it][1] = asm_load16(rb + 4, off);
+      res[it][0] = load16(rb, off);
+      res[it][1] = load16(rb + 4, off);
     }
   };
   auto res_landed = [&]() {

@@ -6,7 +6,7 @@
 # Boxes differ by a few percent in sustained clock, so only runs of ONE call compare.
 var=$1; shift
 for v in "$@"; do
-  env $var=$v python bench.py --chunk 256 --cpu-sample 0 --also-f32-steps 0 --other-configs 0 --from-host-steps 0 --live-traffic 0 ${AB_EXTRA:-} > /tmp/ab.json 2>/tmp/ab.err || tail -3 /tmp/ab.err
+  env $var=$v python bench.py --chunk 256 --cpu-sample 0 --also-f32-steps 0 --other-configs 0 --fast-steps 0 --from-host-steps 0 --live-traffic 0 ${AB_EXTRA:-} > /tmp/ab.json 2>/tmp/ab.err || tail -3 /tmp/ab.err
   python - <<PY
 import json
 d = json.load(open("/tmp/ab.json"))

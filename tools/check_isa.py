@@ -36,7 +36,7 @@ OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 
 # kernel (substring of the mangled name) -> pinned figures.  `None` = not pinned.
 PINNED = {
-    'chain3_kernelILb0': {'mfma': 192, 'lds_dma': 64, 'global_load_x4': 104, 'global_store_x4': 72, 'barriers': 14, 'scratch': 4, 'vmcnt': [0, 1, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30]},
+    'chain3_kernelILb0': {'mfma': 192, 'lds_dma': 64, 'global_load_x4': 104, 'global_store_x4': 72, 'barriers': 14, 'scratch': 4, 'vmcnt': [0, 1, 2, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30]},
     'igemm_split16_pp32_kernel': {'mfma': 576, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
     'igemm_split16_pp32n_kernelILi128': {'mfma': 288, 'lds_dma': 124, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 53, 'scratch': 0, 'vmcnt': [0, 4]},
     'igemm_f16_pp32_kernelILi256': {'mfma': 384, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},

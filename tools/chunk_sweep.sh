@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box sweep of the neurons-per-launch knob (run on the GPU box: gpurun -- 'bash tools/chunk_sweep.sh 640 624 ...').
 for c in "$@"; do
-  python bench.py --chunk $c --cpu-sample 0 --also-f32-steps 0 --other-configs 0 --from-host-steps 0 --live-traffic 0 > /tmp/cs.json 2>/dev/null
+  python bench.py --chunk $c --cpu-sample 0 --also-f32-steps 0 --other-configs 0 --fast-steps 0 --from-host-steps 0 --live-traffic 0 > /tmp/cs.json 2>/dev/null
   python - $c <<'PY'
 import json, sys
 d = json.loads(open('/tmp/cs.json').read().strip().splitlines()[-1])

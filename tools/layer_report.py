@@ -16,6 +16,7 @@ import sys
 
 
 GEMM_LIKE = ("name like '%igemm%' or name like '%conv3x3%' or name like '%chain_kernel%' "
+             "or name like '%chain3_kernel%' "
              "or name like '%stem_fused%' or name like '%conv3_p64%'")
 
 

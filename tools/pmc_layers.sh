@@ -4,7 +4,7 @@
 cd /root/repo
 for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmcl_$c
-  timeout 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmcl_$c -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 2>&1 | tail -1 | cut -c1-80
+  timeout 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmcl_$c -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 2>&1 | tail -1 | cut -c1-80
   cd /root/repo
   f=$(find /tmp/pmcl_$c -name "*.db" | head -1)
   python - "$f" $c > gpurun_out/pmc_dispatch_$c.txt <<'PY'
@@ -15,7 +15,7 @@ tables = [r[0] for r in db.execute("select name from sqlite_master where type in
 cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
 print('#', cols)
 q = ("select dispatch_id, kernel_name, sum(value) from counters_collection where kernel_name like '%igemm%' "
-     "or kernel_name like '%chain_kernel%' or kernel_name like '%stem_fused%' or kernel_name like '%conv3_p64%' "
+     "or kernel_name like '%chain_kernel%' or kernel_name like '%chain3_kernel%' or kernel_name like '%stem_fused%' or kernel_name like '%conv3_p64%' "
      "group by dispatch_id, kernel_name order by dispatch_id")
 for r in db.execute(q):
     print(r[0], r[1].split('(')[0].replace(' ', ''), r[2])
@@ -34,7 +34,7 @@ def load(c):
     return rows
 F, W = load('FETCH_SIZE'), load('WRITE_SIZE')
 n = 3840
-layers = build_layers(n, True, True, False)  # split mode: folded downsamples, layer1/2 chains
+layers = build_layers(n, True, True, True)  # split mode: folded downsamples, layer1/2/3 chains
 agg = {}
 for (name, m, nn, k, fl), f, w in zip(layers, F, W):
     a = agg.setdefault(group_key(name), [0, 0.0, 0.0, m, nn, k, f[1][:40]])

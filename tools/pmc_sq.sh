@@ -4,7 +4,7 @@
 out=$1; ctrs=$2
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc
-timeout 500 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 2>&1 | tail -1 | cut -c1-120
+timeout 500 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 2>&1 | tail -1 | cut -c1-120
 cd /root/repo
 f=$(find /tmp/pmc -name "*.db" | head -1)
 python - > gpurun_out/${out}_pmc.txt <<PY
@@ -15,7 +15,7 @@ print([t for t in tabs if 'pmc' in t.lower() or 'counter' in t.lower()])
 try:
     q="select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name order by 1,2"
     for r in db.execute(q):
-        if any(k in r[0] for k in ('igemm', 'chain_kernel', 'stem_fused', 'conv3_p64')): print(r[0][:70], r[1], r[2], r[3])
+        if any(k in r[0] for k in ('igemm', 'chain_kernel', 'chain3_kernel', 'stem_fused', 'conv3_p64')): print(r[0][:70], r[1], r[2], r[3])
 except Exception as e:
     print('ERR', e)
     for t in tabs: 

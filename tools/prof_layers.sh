@@ -4,7 +4,7 @@
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
-timeout 500 rocprofv3 --kernel-trace -d /tmp/prof -o bench -- python /root/repo/bench.py --chunk 256 --steps 3 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 "$@" 2>&1 | tail -1 | cut -c1-150
+timeout 500 rocprofv3 --kernel-trace -d /tmp/prof -o bench -- python /root/repo/bench.py --chunk 256 --steps 3 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 "$@" 2>&1 | tail -1 | cut -c1-150
 cd /root/repo
 f=$(find /tmp/prof -name "*.db" | head -1)
 python tools/layer_report.py $f 3840 3 1 1 > gpurun_out/${out}_layers.txt

@@ -12,14 +12,14 @@ import re
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out'
-dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r4_hbm_traffic.json'
+dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles/r5_hbm_traffic.json'
 
 
 def read(counter):
     table = {}
     for line in open(f'{src}/traffic_{counter}.txt'):
         name, ctr, launches, total = line.rsplit(None, 3)
-        if ctr != counter or not any(k in name for k in ('igemm', 'chain_kernel', 'stem_fused', 'conv3_p64')):
+        if ctr != counter or not any(k in name for k in ('igemm', 'chain_kernel', 'chain3_kernel', 'stem_fused', 'conv3_p64')):
             continue
         key = re.sub(r'^void_milan::|\(.*$|_', '', name)
         table[key] = (int(launches), float(total))
