@@ -244,28 +244,53 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
 #pragma unroll
     for (int k = 0; k < 8; ++k) wa[k] = fa[k] + (unsigned)soff;
   };
-  // weight fragments of k-step s4 of tile 0 / tile 1 of the current pair (wa[] points at tile
-  // 0; tile 1 is +16 KB and the second 32-row MFMA tile +8 KB: immediates)
-  auto rd_w0 = [&](int buf, int s4) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
+  // Weight fragments of step i = 0..7 of the current pair (tile i >> 2, k-step i & 3; wa[] points
+  // at tile 0, tile 1 is +16 KB and the second 32-row MFMA tile +8 KB: immediates), the "lo"
+  // and the "hi" pair separately.  A step multiplies lo . h first and hi . l, hi . h after it, so
+  // the lo registers of a buffer are free after the step's second MFMA and the hi registers
+  // after its sixth: each pair is re-requested for step i + 2 right there -- 1.3-1.7 steps of
+  // look-ahead out of two buffers (requesting a whole step at the top of the previous one gave
+  // 1.0: ~60 cycles of LDS stall per step, profiles/r5_experiments.txt A).
+  auto rd_lo = [&](int buf, int i) {
+    const int s4 = i & 3;
+    if (i < 4) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
+    } else {
+      asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
+    }
   };
-  auto rd_w1 = [&](int buf, int s4) {
-    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(wf[buf][1]) : "v"(wa[2 * s4 + 1]) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(wf[buf][3]) : "v"(wa[2 * s4 + 1]) : "memory");
+  auto rd_hi = [&](int buf, int i) {
+    const int s4 = i & 3;
+    if (i < 4) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
+    } else {
+      asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(wf[buf][0]) : "v"(wa[2 * s4]) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(wf[buf][2]) : "v"(wa[2 * s4]) : "memory");
+    }
   };
-  auto wait_w = [&](int buf, bool last) {
-    if (last)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(4)"
-                   : "+v"(wf[buf][0]), "+v"(wf[buf][1]), "+v"(wf[buf][2]), "+v"(wf[buf][3]) :: "memory");
+  // Requests are issued in the order lo(0) hi(0) lo(1) hi(1) | lo(2) hi(2) lo(3) ... (LDS returns in
+  // order): before step i's first MFMA everything up to lo(i) has landed, before its third
+  // everything up to hi(i); `n` = the reads allowed to be still in flight (6 6 / .. / 4 / 2 0)
+  auto wait_lo = [&](int buf, int n) {
+    switch (n) {
+      case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[buf][1]), "+v"(wf[buf][3]) :: "memory"); break;
+      case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wf[buf][1]), "+v"(wf[buf][3]) :: "memory"); break;
+      default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[buf][1]), "+v"(wf[buf][3]) :: "memory"); break;
+    }
   };
+  auto wait_hi = [&](int buf, int n) {
+    switch (n) {
+      case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[buf][0]), "+v"(wf[buf][2]) :: "memory"); break;
+      case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[buf][0]), "+v"(wf[buf][2]) :: "memory"); break;
+      default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[buf][0]), "+v"(wf[buf][2]) :: "memory"); break;
+    }
+  };
+  // (reads in flight behind lo(i) / hi(i) at the two wait points of step i)
+  auto lo_inflight = [](int i) { return i <= 6 ? 6 : 2; };
+  auto hi_inflight = [](int i) { return i < 6 ? 6 : (i == 6 ? 4 : 0); };
   // x' fragments of a slab (four k-steps x (hi, lo)): read ONCE per slab and kept for its
   // eight output tiles (re-reading them per tile pair was a third of the reduce phase's LDS
   // traffic, and the latency of the weight reads rides on that traffic)
@@ -407,21 +432,24 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
           if (s < NSLAB) {
             // eight k-steps (two tiles) in one software pipeline: the fragments of step i + 1
             // are requested before step i multiplies
+            __builtin_amdgcn_s_setprio(1);   // the multiplying wave outranks its partner's VALU / DMA issue
             set_pair(q);
-            rd_w0(0, 0);
+            rd_lo(0, 0); rd_hi(0, 0); rd_lo(1, 1); rd_hi(1, 1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               const int ks = 8 * hh + i, b = i & 1;
-              if (i < 3) rd_w0(b ^ 1, i + 1);
-              else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
-              wait_w(b, i == 7);
+              wait_lo(b, lo_inflight(i));
               acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(t2h[ks]), acc3[0], 0, 0, 0);
               acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(t2h[ks]), acc3[1], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (i < 6) rd_lo(b, i + 2);
+              wait_hi(b, hi_inflight(i));
               acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2l[ks]), acc3[0], 0, 0, 0);
               acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2l[ks]), acc3[1], 0, 0, 0);
               acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(t2h[ks]), acc3[0], 0, 0, 0);
               acc3[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(t2h[ks]), acc3[1], 0, 0, 0);
               __builtin_amdgcn_sched_barrier(0);
+              if (i < 6) rd_hi(b, i + 2);
             }
           }
           // own pieces of pair q + 1 (issued at the top of half-slot 4 s - 1): only the six
@@ -431,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
           // here (E(15) was the last reader of the current ones) and travel under the R-wave's
           // last epilogue / product
           if (hh == 1 && s == NSLAB && has_next) load_t2(ntile);
+          __builtin_amdgcn_s_setprio(0);
           end_half(2);
         }
         // ---- half-slots 4 s + 2, 4 s + 3: weights for E(s + 1); epilogue of channels 0..31 ----
@@ -562,21 +591,24 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
         for (int hh = 0; hh < 2; ++hh) {
           const int q = 4 * s + 2 + hh;
           if (s >= 1) {
+            __builtin_amdgcn_s_setprio(1);   // the multiplying wave outranks its partner's VALU / DMA issue
             set_pair(q);
-            rd_w0(0, 0);
+            rd_lo(0, 0); rd_hi(0, 0); rd_lo(1, 1); rd_hi(1, 1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               const int b = i & 1, u0 = 2 * (2 * hh + (i >> 2)), k4 = i & 3;
-              if (i < 3) rd_w0(b ^ 1, i + 1);
-              else if (i < 7) rd_w1(b ^ 1, (i + 1) & 3);
-              wait_w(b, i == 7);
+              wait_lo(b, lo_inflight(i));
               acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][1]), h8(xs[k4][0]), acc1[u0], 0, 0, 0);
               acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][3]), h8(xs[k4][0]), acc1[u0 + 1], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (i < 6) rd_lo(b, i + 2);
+              wait_hi(b, hi_inflight(i));
               acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xs[k4][1]), acc1[u0], 0, 0, 0);
               acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xs[k4][1]), acc1[u0 + 1], 0, 0, 0);
               acc1[u0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][0]), h8(xs[k4][0]), acc1[u0], 0, 0, 0);
               acc1[u0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wf[b][2]), h8(xs[k4][0]), acc1[u0 + 1], 0, 0, 0);
               __builtin_amdgcn_sched_barrier(0);
+              if (i < 6) rd_hi(b, i + 2);
             }
           }
           if (s == 0 && pending) final_quarter(2 + hh);
@@ -584,6 +616,7 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
             if (s < NSLAB) wait_vmcnt<6>();
             else wait_vmcnt<0>();
           }
+          __builtin_amdgcn_s_setprio(0);
           end_half(2);
         }
       }
