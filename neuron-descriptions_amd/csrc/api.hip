@@ -412,9 +412,10 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       const float* residual, float* y, int precision,
                       milan_stream stream) {
   MILAN_REQUIRE(x && weight_oihw && y, MILAN_ERR_ARG, "conv2d: null argument");
-  // precision 3 (test hook only): split-f16 with the LDS-strip 3x3 kernel forced
-  const bool force_strip = precision == 3;
-  if (force_strip) precision = MILAN_PRECISION_SPLIT_F16;
+  // precision 3 (test hook only): split-f16 with the LDS-strip 3x3 kernel forced;
+  // precision 4 (test hook only): split-f16 with k in tap-major order (GemmArgs::Wt unset)
+  const bool force_strip = precision == 3, tap_major = precision == 4;
+  if (force_strip || tap_major) precision = MILAN_PRECISION_SPLIT_F16;
   MILAN_REQUIRE(!force_strip || MILAN_EXPERIMENTS, MILAN_ERR_ARG,
                 "conv2d: the LDS-strip 3x3 kernel is only in an experiments build "
                 "(make EXPERIMENTS=1)");
@@ -424,7 +425,7 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                 "conv2d: cin must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   const int K = kh * kw * cin, Kp = (K + 31) / 32 * 32;
-  float *wp = nullptr, *zero = nullptr, *xs = nullptr, *wsp = nullptr, *ws3 = nullptr;
+  float *wp = nullptr, *zero = nullptr, *xs = nullptr, *wsp = nullptr, *ws3 = nullptr, *wst = nullptr;
   MILAN_CHECK_HIP(hipMalloc((void**)&wp, sizeof(float) * (size_t)cout * Kp));
   MILAN_CHECK_HIP(hipMalloc((void**)&zero, 256));
   MILAN_CHECK_HIP(hipMemsetAsync(zero, 0, 256, s));
@@ -452,6 +453,13 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
           r = split_weight_into(wp, cout, Kp, wsp, &g.acc_scale,
                                 reinterpret_cast<unsigned int*>(zero) + 32, s);
         g.A = xs; g.W = wsp; g.a_split = 1;
+        if (r == 0 && !tap_major && kh * kw > 1 && kh * kw <= 32 && K == Kp) {
+          // the trunk's k x k convs run in (slice, tap, channel) order: test that one
+          if (hipMalloc((void**)&wst, sizeof(float) * (size_t)cout * Kp) == hipSuccess) {
+            r = make_slice_major(wsp, cout, kh * kw, cin, 4, 2, wst, s);
+            g.Wt = wst;
+          }
+        }
         if (MILAN_EXPERIMENTS && r == 0 && kh == 3 && kw == 3 && stride == 1 &&
             pad == 1 && K == Kp) {
           // the trunk's 3x3 convs run on the LDS-strip kernel: test it the same way
@@ -471,6 +479,7 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
   if (xs) (void)hipFree(xs);
   if (wsp) (void)hipFree(wsp);
   if (ws3) (void)hipFree(ws3);
+  if (wst) (void)hipFree(wst);
   if (r == 0 && e != hipSuccess) {
     set_error("conv2d: %s", hipGetErrorString(e));
     r = (int)e;

@@ -115,6 +115,11 @@ struct GemmArgs {
                       // element count: a row of C f16 channels is addressed exactly like a
                       // split-format row of C / 2 channels, and the ping-pong kernel multiplies
                       // "hi . hi + lo . lo" of that pretended row = one f16 MFMA per 16 real k
+  const float* Wt;    // k x k convs, Cin % 32 == 0: the rows of W with k running (32-channel slice, tap,
+                      // channel) instead of (tap, channel) -- ConvW::wst.  The ping-pong kernel then
+                      // asks for the KH * KW shifted copies of a slice in CONSECUTIVE k-tile pairs:
+                      // they hit L2 instead of crossing the fabric once per tap (gemm.hip, TAPI)
+  int tap_inner;      // filled by the launcher: this launch runs in that order
 };
 
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2, OUT_F16 = 3 };
@@ -261,6 +266,8 @@ struct ConvW {
   float* bias = nullptr;  // folded BN shift, [Cout] (nullptr for raw stem)
   float* bias_s = nullptr;  // bias x activation scale (split-f16 trunk, see milan_ctx::act_scale)
   float* wf = nullptr;      // fast mode: the hi halves of `ws` as plain f16 rows [Cout][Kp] (2 B each)
+  float* wst = nullptr;     // k x k convs: `ws` with k in (32-channel slice, tap, channel) order (GemmArgs::Wt)
+  float* wft = nullptr;     // ... `wf` in (64-channel slice, tap, channel) order
   int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, K = 0, Kp = 0;
   int cin_real = 0;  // channels before padding to a multiple of 4
 };
@@ -467,6 +474,10 @@ int pack_conv_plain(const float* w_oihw, int cout, int cin, int kh, int kw,
 int encoder_finalize(milan_ctx* c, hipStream_t s);
 int encoder_rescale(milan_ctx* c, hipStream_t s);
 // split 3x3 weights [n][tap][Cin] -> chunk-major [n][Cin/16][tap][16]
+// packed conv rows [cout][taps][cin] -> [cout][cin / (8 gps)][taps][8 gps] in 8-channel groups of
+// `gb` 16-byte pieces (2: split format, 1: plain f16) -- GemmArgs::Wt (gps 4 / 8)
+int make_slice_major(const float* ws, int cout, int taps, int cin, int gps, int gb, float* dst,
+                     hipStream_t s);
 int make_chunk_major(const float* ws, int cout, int cin, float* dst,
                      hipStream_t s);
 size_t encoder_workspace(const milan_ctx* c, int n_images, int H, int W);

@@ -66,34 +66,41 @@ static const Tensor* find(milan_ctx* c, const std::string& name) {
   return it == c->raw.end() ? nullptr : &it->second;
 }
 
-// dst[n][(chunk*9 + tap)*2 + g] = src[n][tap*(Cin/8) + 2*chunk + g] in units of
-// one 8-channel split group (8 floats = [hi x8 | lo x8])
-__global__ void chunk_major_kernel(const float* __restrict__ src, int cout, int cin,
-                                   float* __restrict__ dst) {
-  const int gpr = 9 * (cin / 8);  // groups per row
+// Slice-major k order of a k x k conv's packed rows: 8-channel groups of `gb` 16-byte pieces
+// (2: split format, 1: plain f16) move from [tap][Cin / 8] to [Cin / (8 gps)][tap][gps]:
+//   dst[n][(slice * taps + tap) * gps + gi] = src[n][tap * (Cin / 8) + slice * gps + gi]
+__global__ void slice_major_kernel(const float* __restrict__ src, int cout, int taps, int cin,
+                                   int gps, int gb, float* __restrict__ dst) {
+  const int gpt = cin / 8;       // groups per tap
+  const int gpr = taps * gpt;    // groups per row
   const long total = (long)cout * gpr;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const long n = idx / gpr;
     const int d = idx - n * gpr;
-    const int gsel = d & 1, ct = d >> 1;
-    const int chunk = ct / 9, tap = ct - chunk * 9;
-    const float4* sp = reinterpret_cast<const float4*>(
-        src + (n * gpr + tap * (cin / 8) + 2 * chunk + gsel) * 8);
-    float4* dp = reinterpret_cast<float4*>(dst + idx * 8);
-    dp[0] = sp[0];
-    dp[1] = sp[1];
+    const int gi = d % gps, st = d / gps;
+    const int slice = st / taps, tap = st - slice * taps;
+    const float4* sp = reinterpret_cast<const float4*>(src) +
+                       (n * gpr + tap * gpt + slice * gps + gi) * gb;
+    float4* dp = reinterpret_cast<float4*>(dst) + idx * gb;
+    for (int e = 0; e < gb; ++e) dp[e] = sp[e];
   }
 }
 
-int make_chunk_major(const float* ws, int cout, int cin, float* dst,
+int make_slice_major(const float* ws, int cout, int taps, int cin, int gps, int gb, float* dst,
                      hipStream_t s) {
-  const long groups = (long)cout * 9 * (cin / 8);
+  const long groups = (long)cout * taps * (cin / 8);
   const int blocks = (int)((groups + 255) / 256 < 4096 ? (groups + 255) / 256 : 4096);
-  hipLaunchKernelGGL(chunk_major_kernel, dim3(blocks), dim3(256), 0, s, ws, cout,
-                     cin, dst);
+  hipLaunchKernelGGL(slice_major_kernel, dim3(blocks), dim3(256), 0, s, ws, cout, taps, cin,
+                     gps, gb, dst);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+// (the experiments build's LDS-strip kernel: 16-channel chunks of a 3x3 conv)
+int make_chunk_major(const float* ws, int cout, int cin, float* dst,
+                     hipStream_t s) {
+  return make_slice_major(ws, cout, 9, cin, 2, 2, dst, s);
 }
 
 __global__ void scale_vec_kernel(const float* __restrict__ a, float m, int n,
@@ -184,6 +191,16 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
                                 &out->ws_inv, s));
     if (out->ws) MILAN_TRY(scaled_copy(c, out->bias, out->cout, &out->bias_s, s));
     MILAN_TRY(make_f16_weight(c, out, s));
+    if (out->ws && out->kh * out->kw > 1 && out->kh * out->kw <= 32 && out->Kp == out->K) {
+      // (32-channel slice, tap, channel) order for the ping-pong kernel (GemmArgs::Wt)
+      const int taps = out->kh * out->kw;
+      MILAN_TRY(dev_alloc(c, (void**)&out->wst, sizeof(float) * (size_t)out->cout * out->Kp));
+      MILAN_TRY(make_slice_major(out->ws, out->cout, taps, out->cin, 4, 2, out->wst, s));
+      if (out->wf) {
+        MILAN_TRY(dev_alloc(c, (void**)&out->wft, sizeof(float) * (size_t)out->cout * out->Kp / 2));
+        MILAN_TRY(make_slice_major(out->wf, out->cout, taps, out->cin, 8, 1, out->wft, s));
+      }
+    }
 #if MILAN_EXPERIMENTS
     if (out->ws && out->kh == 3 && out->kw == 3 && out->Kp == out->K &&
         out->cin % 16 == 0) {
@@ -905,6 +922,7 @@ static GemmArgs conv_args(const ConvW& cw, const float* in, int n, int H, int W,
     g.W = cw.ws; g.a_split = 1; g.out_split = 1; g.aux_split = aux != nullptr;
     g.acc_scale = cw.ws_inv;
     g.W3 = cw.ws3;
+    g.Wt = cw.wst;
     // the ResNet trunks keep split activations in the context's activation scale
     if (scaled_bias && cw.bias_s) g.bias = cw.bias_s;
   }
@@ -917,7 +935,7 @@ static GemmArgs conv_args_f16(const ConvW& cw, const float* in, int n, int H, in
                               float* out, int epi, const float* aux, const float* zero,
                               int* Ho, int* Wo) {
   GemmArgs g = conv_args(cw, in, n, H, W, out, epi, aux, zero, Ho, Wo, true);
-  g.W = cw.wf; g.W3 = nullptr;
+  g.W = cw.wf; g.W3 = nullptr; g.Wt = cw.wft;
   g.f16 = 1; g.out_split = 0; g.aux_split = 0;
   g.Cin = cw.cin / 2; g.K = cw.K / 2; g.Kp = cw.Kp / 2;
   g.a_pix_stride = cw.cin / 2;

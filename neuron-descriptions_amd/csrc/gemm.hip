@@ -1634,6 +1634,7 @@ struct PpLoader {
   __amdgpu_buffer_rsrc_t srd_a, srd_a2, srd_w, cur_srd;
   unsigned row_off[4], row_off2[4], voff[4], vb[4];
   int hw0[4];  // (hi0 << 16) | (wi0 & 0xffff): the row's first input pixel (may be negative)
+  unsigned mask[4];  // TAPI: bit kh * KW + kw = that tap of the row is inside the image
   int ia, iw, is_kh, is_kw, is_cin0, seg_soff, cin_limit;
 };
 
@@ -1646,7 +1647,14 @@ struct PpLoader {
 // N = 128 layers of layer2 and the odd-width products): wave tiles 64 x 64 (4 x 2 waves), the
 // SAME loader -- W rows 128..255 of a slot carry out-of-range offsets, for which the DMA writes
 // zeros without a fetch -- so every counted wait is the 256-column kernel's.
-template <int BNW, bool F16 = false>
+// TAPI (GemmArgs::tap_inner): k runs (32-channel slice, tap, channel).  The KH * KW shifted
+// copies of a slice are then requested in consecutive pairs -- the second to ninth find their
+// lines in L2 (tap-major, a line is asked for again 8 pairs = 8 x 32 workgroups x 32 KB later
+// and has left it: layer3's 3x3 convs pulled their input 8.3 x over the fabric).  The in-image
+// test of a row's taps is a 9-bit mask made once per tile, the per-pair step is 12 VALU + a
+// few scalar instructions in the read phase.  NOT the tap-major bits (the order of the fp32
+// additions differs); compile-time so that the other launches keep their loop.
+template <int BNW, bool F16 = false, bool TAPI = false>
 __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int tid, bool prefetched,
                                                   bool has_next, int ntile_m, int ntile_n) {
   const GemmArgs g = reload_gemm_args();
@@ -1667,6 +1675,13 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
 
   // ---- loader: piece `it` of this wave = rows it * 64 + wave * 8 .. + 7, one 128-B line each
   auto set_tap = [&](PpLoader& L) {  // per-lane bounds of tap (is_kh, is_kw): once per tap
+    if constexpr (TAPI) {
+      const int t = L.is_kh * g.KW + L.is_kw;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) L.voff[it] = (L.mask[it] >> t) & 1u ? L.row_off[it] : OOB;
+      L.seg_soff = (int)((((long)L.is_kh * g.Wd + L.is_kw) * g.a_pix_stride) * 4);
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int hi = (L.hw0[it] >> 16) + L.is_kh, wi = (int)(short)(L.hw0[it] & 0xffff) + L.is_kw;
@@ -1709,6 +1724,14 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
       const int wo = rem - ho * g.Wo;
       const int hi0 = ho * g.stride - g.pad, wi0 = wo * g.stride - g.pad;
       L.hw0[it] = (hi0 << 16) | (wi0 & 0xffff);
+      if constexpr (TAPI) {
+        unsigned m = 0;
+        for (int kh = 0, t = 0; kh < g.KH; ++kh)
+          for (int kw = 0; kw < g.KW; ++kw, ++t)
+            m |= (unsigned)((unsigned)(hi0 + kh) < (unsigned)g.H &&
+                            (unsigned)(wi0 + kw) < (unsigned)g.Wd) << t;
+        L.mask[it] = m;
+      }
       L.row_off[it] = ok ? (unsigned)(((long)dimg * g.a_img_stride +
                                        ((long)hi0 * g.Wd + wi0) * g.a_pix_stride + bias + q * 4) * 4)
                          : OOB;
@@ -1737,6 +1760,17 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
       for (int it = 0; it < 4; ++it)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(L.cur_srd, (LDS_AS void*)(dst + it * (64 * BKP)), 16,
                                                  L.voff[it], soff, 0, 0);
+    }
+    if constexpr (TAPI) {
+      if (L.ia + 1 < np) {
+        ++L.ia;
+        if (++L.is_kw == g.KW) {
+          L.is_kw = 0;
+          if (++L.is_kh == g.KH) { L.is_kh = 0; L.is_cin0 += BKP; }
+        }
+        set_tap(L);
+      }
+      return;
     }
     if (L.ia + 1 < np) {  // past the end the last pair is fetched again (constant vmcnt counts)
       ++L.ia;
@@ -2015,8 +2049,22 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, 
   split16_pp32_tile<256>(tile_m, tile_n, tid, false, false, tile_m, tile_n);
 }
 
-// fast mode (GemmArgs::f16): the same tile with one MFMA per 16 real k
+// k x k convs in (slice, tap, channel) order (GemmArgs::tap_inner)
 template <int BNW>
+__global__ __launch_bounds__(512, 2) void igemm_split16_pp32t_kernel(GemmArgs g, int tiles_m,
+                                                                     int tiles_n) {
+  const int T = tiles_m * tiles_n;
+  const int q = blockIdx.x;
+  if (q >= T) return;
+  const int tile = xcd_tile(q, T);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  split16_pp32_tile<BNW, false, true>(tile_m, tile_n, tid, false, false, tile_m, tile_n);
+}
+
+// fast mode (GemmArgs::f16): the same tile with one MFMA per 16 real k
+template <int BNW, bool TAPI>
 __global__ __launch_bounds__(512, 2) void igemm_f16_pp32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   const int T = tiles_m * tiles_n;
   const int q = blockIdx.x;
@@ -2025,7 +2073,7 @@ __global__ __launch_bounds__(512, 2) void igemm_f16_pp32_kernel(GemmArgs g, int 
   const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-  split16_pp32_tile<BNW, true>(tile_m, tile_n, tid, false, false, tile_m, tile_n);
+  split16_pp32_tile<BNW, true, TAPI>(tile_m, tile_n, tid, false, false, tile_m, tile_n);
 }
 
 __global__ __launch_bounds__(512, 2) void igemm_split16_pp_kernel(GemmArgs g, int tiles_m,
@@ -2563,10 +2611,29 @@ static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
 
 // the ping-pong form of the 256 x 256 tile (4-slot ring: 128 KB of LDS)
 // ... staged in k-tile pairs (whole 128-byte lines): A ring 3 x 32 KB + W ring 2 x 32 KB
+// k x k convs whose weights exist in (slice, tap, channel) order run in that order
+// (MILAN_TAP_INNER=0: tap-major, the round-4 bits; A/B timing and traffic)
+static bool tap_inner_wanted(const GemmArgs& g) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MILAN_TAP_INNER"); on = e ? atoi(e) : 1; }
+  return on && g.Wt && !g.A2 && g.KH * g.KW > 1 && g.KH * g.KW <= 32 && g.K == g.Kp;
+}
+
 template <int BNW>
 static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + BNW - 1) / BNW;
   const size_t lds = size_t(5) * 256 * 32 * sizeof(float);
+  if (tap_inner_wanted(g)) {
+    GemmArgs t = g;
+    t.W = g.Wt;
+    t.tap_inner = 1;
+    profile_tag_kernel(BNW == 256 ? MILAN_KERNEL_PP32_256 : MILAN_KERNEL_PP32_128);
+    auto kern = igemm_split16_pp32t_kernel<BNW>;
+    MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, t, tiles_m, tiles_n);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   int ncus = 0;
   MILAN_TRY(device_cus8(&ncus));
   int grid = tiles_m * tiles_n;
@@ -2597,7 +2664,17 @@ static int launch_f16_pp32(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + BNW - 1) / BNW;
   const size_t lds = size_t(5) * 256 * 32 * sizeof(float);
   profile_tag_kernel(MILAN_KERNEL_F16);
-  auto kern = igemm_f16_pp32_kernel<BNW>;
+  if (tap_inner_wanted(g)) {
+    GemmArgs t = g;
+    t.W = g.Wt;
+    t.tap_inner = 1;
+    auto kern = igemm_f16_pp32_kernel<BNW, true>;
+    MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, t, tiles_m, tiles_n);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  auto kern = igemm_f16_pp32_kernel<BNW, false>;
   MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, g, tiles_m, tiles_n);
   MILAN_CHECK_HIP(hipGetLastError());

@@ -44,7 +44,7 @@ class SketchOp(ctypes.Structure):
 
 DRAW_BIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 # conv2d_nhwc test hook only: split_f16 with the LDS-strip 3x3 kernel forced
-_CONV_PRECISIONS = dict(f32=0, split_f16=1, split_f16_strip=3)
+_CONV_PRECISIONS = dict(f32=0, split_f16=1, split_f16_strip=3, split_f16_tap_major=4)
 DTYPE_U8, DTYPE_F32 = 0, 1
 
 ERR_ARG, ERR_SHAPE, ERR_STATE, ERR_WORKSPACE, ERR_NO_LM = -1, -2, -3, -4, -5

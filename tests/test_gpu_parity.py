@@ -50,6 +50,7 @@ CONV_CASES = [
     (5, 7, 7, 64, 512, 3, 1, 1),     # layer4-like: 4 images per tile
     (1, 9, 37, 32, 128, 3, 1, 1),    # oblong, ragged last tile
     (2, 61, 63, 32, 128, 3, 1, 1),   # the widest image the strip holds (W + 1 <= 64)
+    (2, 27, 27, 64, 192, 5, 1, 2),   # AlexNet features.3: 25 taps
 ]
 
 
@@ -445,6 +446,35 @@ def test_split_f16_conv_error_is_fp32_class(dev, case):
     scale = float(want.abs().max())
     assert errs['split_f16'] <= max(4 * errs['f32'], 2e-6 * scale), errs
     assert errs['split_f16'] <= 1e-5 * scale, errs
+
+
+KXK_CASES = [c for c in SPLIT_CASES if c[5] > 1]
+
+
+@pytest.mark.parametrize('case', KXK_CASES)
+def test_tap_inner_k_order_is_the_same_class_as_tap_major(dev, case):
+    """The trunk's k x k convs run with k in (32-channel slice, tap, channel) order (every
+    shifted copy of a slice is requested in consecutive k-tile pairs and hits L2: layer3's
+    3x3 convs pulled their input 8.3 x over the fabric in tap-major order).  Same products,
+    another order of the fp32 additions: both orders are fp32-class against fp64, over
+    strides, pads, image borders inside a tile and ragged last tiles."""
+    assert len(KXK_CASES) >= 4
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(23 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k))**.5
+    b = torch.randn(cout, generator=g)
+    want = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    scale = float(want.abs().max())
+    err = {}
+    for prec in ('split_f16', 'split_f16_tap_major', 'f32'):
+        got = hip.conv2d_nhwc(x_nhwc, wt.to(dev), b.to(dev), stride, pad,
+                              precision=prec).permute(0, 3, 1, 2).cpu().double()
+        err[prec] = float((got - want).abs().max())
+    print(case, {p: f'{e / scale:.2e}' for p, e in err.items()})
+    assert err['split_f16'] <= max(2 * err['split_f16_tap_major'], 2e-6 * scale), err
+    assert err['split_f16'] <= max(4 * err['f32'], 2e-6 * scale), err
 
 
 STRIP_CASES = [c for c in CONV_CASES
