@@ -255,12 +255,17 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1,
  *   MILAN_FUSE_CONV3  the 64 -> 64 channel 3x3 convolutions of layer1 as a persistent
  *                     kernel with register-resident weights and an LDS-resident input
  *                     tile (csrc/conv3.hip) instead of the implicit GEMM.
- * Default: all four (environment MILAN_CHAIN=<flags> overrides at context creation). */
+ *   MILAN_FUSE_SKIP_EMPTY  exemplars whose mask is all zero pool exact zeros at every
+ *                     pyramid level whatever the trunk computes (src/milan/encoders.py:
+ *                     310-317): they are left out of the trunk pass (uint8 images; one
+ *                     4-byte read-back per encoder pass).
+ * Default: all five (environment MILAN_CHAIN=<flags> overrides at context creation). */
 enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
        MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): the role ping-pong of csrc/chain3.hip
                                       (round 5) */
        MILAN_FUSE_STEM = 4,
-       MILAN_FUSE_CONV3 = 8 };     /* layer1's 3x3 convs: weights in registers (csrc/conv3.hip) */
+       MILAN_FUSE_CONV3 = 8,       /* layer1's 3x3 convs: weights in registers (csrc/conv3.hip) */
+       MILAN_FUSE_SKIP_EMPTY = 16 };
 int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);

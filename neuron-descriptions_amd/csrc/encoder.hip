@@ -408,7 +408,8 @@ __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
                                   float4* __restrict__ out,
                                   const void* __restrict__ mul = nullptr,
                                   int mul_u8 = 1, int* __restrict__ poison = nullptr,
-                                  unsigned* __restrict__ status = nullptr) {
+                                  unsigned* __restrict__ status = nullptr,
+                                  const int* __restrict__ order = nullptr) {
   // the byte->float product is rounded on its own, as in the reference: no
   // contraction into the mean subtraction
 #pragma clang fp contract(off)
@@ -416,7 +417,7 @@ __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n_pix_total;
        p += (long)gridDim.x * blockDim.x) {
     const long n = p / hw, r = p - n * hw;
-    const T* base = img + n * 3 * hw + r;
+    const T* base = img + (order ? (long)order[n] : n) * 3 * hw + r;
     float v0, v1, v2;
     if constexpr (sizeof(T) == 1) {
       v0 = (float)base[0] * inv255;
@@ -532,7 +533,8 @@ __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups
                                         float* __restrict__ out,
                                         const void* __restrict__ mul = nullptr,
                                         int mul_u8 = 1, int* __restrict__ poison = nullptr,
-                                        unsigned* __restrict__ status = nullptr) {
+                                        unsigned* __restrict__ status = nullptr,
+                                        const int* __restrict__ order = nullptr) {
 #pragma clang fp contract(off)  // see preprocess_kernel
   const float inv255 = (float)(1.0 / 255.0);
   const long hw = (long)H * W;
@@ -543,7 +545,8 @@ __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups
     const long row = q / G;            // img * H + y
     const long n = row / H;
     const int y = row - n * H;
-    const T* base = img + n * 3 * hw + (long)y * W;
+    // (`order`: batch slot n holds image order[n]; never together with `mul` / `poison`)
+    const T* base = img + (order ? (long)order[n] : n) * 3 * hw + (long)y * W;
     float v[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -733,6 +736,46 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(
   }
 }
 
+// An image whose weight list is empty at EVERY pyramid level (an all-zero mask) pools
+// x * 0: exact zeros whatever the trunk computes (encoders.py:310-317; the reference's
+// isclose rule leaves such a mask un-normalised).  Those images need no trunk pass:
+// order[j] = the j-th image that has work (ascending), bbox_c its bounding box, *count how
+// many there are.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void compact_images_kernel(
+    const int* __restrict__ list_n, int n, const int* __restrict__ bbox,
+    int* __restrict__ order, int* __restrict__ bbox_c, int* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    int any = 0;
+    if (i < n)
+      for (int l = 0; l < 5; ++l) any |= list_n[i * 5 + l];
+    const bool live = any != 0;
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (live) {
+      const int j = off + __popcll(m & ((1ull << lane) - 1ull));
+      order[j] = i;
+      for (int e = 0; e < 4; ++e) bbox_c[j * 4 + e] = bbox[i * 4 + e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = base;
+}
+
 // features[img][col_off + c] = sum_p w[p] * tap[img][p][c]   (encoders.py:317)
 // grid (n_images, ceil(C/64)); 4 waves split the pixel list, lane = channel.
 template <int SPLIT_IN>   // 0: fp32 tap, 1: split format, 2: plain f16 (fast mode)
@@ -740,11 +783,12 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
     const float* __restrict__ tap, int P, int C, int level, Levels lv,
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
     const int* __restrict__ list_n, float* __restrict__ features, int fstride,
-    int col_off, int img0, float inv_scale, const int* __restrict__ poison = nullptr) {
+    int col_off, int img0, float inv_scale, const int* __restrict__ poison = nullptr,
+    const int* __restrict__ order = nullptr) {
   __shared__ float part[4][64];
-  // `tap` points at image img0 of the batch; lists / features are indexed by
-  // the absolute image number
-  const int img = blockIdx.x + img0;
+  // `tap` points at slot img0 of the batch; lists / features are indexed by the image
+  // number (`order`: the batch holds only the images with a non-empty mask, in this order)
+  const int img = order ? order[blockIdx.x + img0] : blockIdx.x + img0;
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
   const int phase = threadIdx.x >> 6;
   const long base = (long)img * lv.per_image + lv.off[level];
@@ -823,6 +867,7 @@ struct EncPlan {
   float* list_w;
   int* bbox;  // [n][4]: level-0 bounding box of the listed pixels
   int* poison;  // [n]: 1 = the image holds a non-finite pixel (float inputs only)
+  int *order, *bbox_c, *count;  // images with a non-empty mask (compact_images_kernel)
 };
 
 static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
@@ -868,6 +913,9 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   pl->list_n = a.get<int>((size_t)n * 5);
   pl->bbox = a.get<int>((size_t)n * 4);
   pl->poison = a.get<int>((size_t)n);
+  pl->order = a.get<int>((size_t)n);
+  pl->bbox_c = a.get<int>((size_t)n * 4);
+  pl->count = a.get<int>(4);
   return 0;
 }
 
@@ -1046,6 +1094,30 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                        pl.list_n, pl.bbox);
   MILAN_CHECK_HIP(hipGetLastError());
 
+  // 1b. images with an all-zero mask pool exact zeros at every level: they stay out of the
+  // trunk pass (MILAN_FUSE_SKIP_EMPTY; uint8 images only -- a float image may hold a NaN
+  // pixel, whose image the reference turns into NaN even under a zero mask).  The batch
+  // below is the `n` images with work, slot j = image order[j]; one 4-byte read-back.
+  const int n_all = n;
+  const int* order = nullptr;
+  if (!spatial && masks != nullptr && image_dtype == MILAN_DTYPE_U8 && c->calib == nullptr &&
+      (c->fusion & MILAN_FUSE_SKIP_EMPTY)) {
+    hipLaunchKernelGGL(compact_images_kernel, dim3(1), dim3(1024), 0, s, pl.list_n, n_all,
+                       pl.bbox, pl.order, pl.bbox_c, pl.count);
+    MILAN_CHECK_HIP(hipGetLastError());
+    int live = n_all;
+    MILAN_CHECK_HIP(hipMemcpyAsync(&live, pl.count, sizeof(int), hipMemcpyDeviceToHost, s));
+    MILAN_CHECK_HIP(hipStreamSynchronize(s));
+    MILAN_REQUIRE(live >= 0 && live <= n_all, MILAN_ERR_STATE, "encode: image compaction failed");
+    if (live < n_all) {
+      MILAN_CHECK_HIP(hipMemsetAsync(features, 0, sizeof(float) * (size_t)n_all * c->d.feature_size, s));
+      if (live == 0) return 0;
+      n = live;
+      order = pl.order;
+    }
+  }
+  const int* const bbox = order ? pl.bbox_c : pl.bbox;
+
   // split-f16 mode needs every bottleneck conv to have a split weight copy
   bool split = c->precision == MILAN_PRECISION_SPLIT_F16 && wd % 8 == 0;
   for (int li = 0; li < 4 && split; ++li)
@@ -1072,7 +1144,8 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (pair_stem && image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_pairs_kernel<uint8_t>, dim3(blocks),
                          dim3(256), 0, s, (const uint8_t*)images, np, H, W, G,
-                         m0, m1, m2, s0, s1, s2, pl.in4, mul, mul_u8, nullptr, c->status);
+                         m0, m1, m2, s0, s1, s2, pl.in4, mul, mul_u8, nullptr, c->status,
+                         order);
     else if (pair_stem)
       hipLaunchKernelGGL(preprocess_pairs_kernel<float>, dim3(blocks), dim3(256),
                          0, s, (const float*)images, np, H, W, G, m0, m1, m2, s0,
@@ -1080,7 +1153,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     else if (image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
                          s, (const uint8_t*)images, np, H * W, m0, m1, m2, s0, s1,
-                         s2, (float4*)pl.in4, mul, mul_u8);
+                         s2, (float4*)pl.in4, mul, mul_u8, nullptr, nullptr, order);
     else
       hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
                          (const float*)images, np, H * W, m0, m1, m2, s0, s1, s2,
@@ -1101,16 +1174,16 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       hipLaunchKernelGGL(masked_pool_kernel<2>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col_off, img0,
-                         1.f / c->act_scale, poison);
+                         1.f / c->act_scale, poison, order);
     else if (split && level > 0)
       hipLaunchKernelGGL(masked_pool_kernel<1>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col_off, img0,
-                         1.f / c->act_scale, poison);
+                         1.f / c->act_scale, poison, order);
     else
       hipLaunchKernelGGL(masked_pool_kernel<0>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off, img0, 1.f, poison);
+                         pl.list_w, pl.list_n, features, F, col_off, img0, 1.f, poison, order);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   };
@@ -1140,7 +1213,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       sa.acc_scale = c->stem_pair.ws_inv;
       sa.scale = c->bn1_scale_s; sa.shift = c->bn1_shift_s;  // (activation scale)
       sa.raw = spatial ? nullptr : pl.raw; sa.y = pl.x0;
-      sa.bbox = spatial ? nullptr : pl.bbox;
+      sa.bbox = spatial ? nullptr : bbox;
       sa.zero = c->zero;
       sa.n = n; sa.H = H; sa.G = G; sa.h1 = pl.h1; sa.w1 = pl.w1;
       sa.hp = pl.hp; sa.wp = pl.wp;
