@@ -250,6 +250,109 @@ __global__ __launch_bounds__(256) void attend_kernel(
   if (lane < k) att[(long)r * k + lane] = e / sum;
 }
 
+// The same for k <= 16 exemplars and A <= 512 attention units (MILAN: 15, 512), one
+// workgroup per NEURON: a wave keeps the neuron's k x A keys in registers (120 per lane) and
+// walks every fourth of its rpn beam rows, so a row costs its 2 KB of q instead of 32 KB of
+// keys out of L2.  The launch of every decode step (32 000 rows x 15 x 512 tanh at beam 50 x
+// 640 neurons) was bound by that and by the ~30 VALU instructions of libm's tanhf:
+// tanh(x) = 1 - 2 / (e^{2x} + 1) on the hardware's exp2 / rcp (1 ulp each) has an absolute
+// error <= 2e-7, the size of one fp32 rounding of the 512-term sum it feeds.  The k wave sums
+// are reduced together, halving the live values per butterfly step (25 cross-lane moves per
+// row instead of 102); lane L ends with the score of exemplar L / 4.
+constexpr int kAttMaxK = 16, kAttMaxE = 8;
+__device__ __forceinline__ float tanh_exp2(float x) {
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // e^{2x}
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+}
+__global__ __launch_bounds__(256) void attend16_kernel(
+    const float* __restrict__ q, const float* __restrict__ keys,
+    const float* __restrict__ w, const float* __restrict__ b, int rows, int rpn,
+    int k, int A, float* __restrict__ att) {
+  const int neuron = blockIdx.x;
+  // (blockIdx.y, wave): which of the neuron's rows, stride 4 gridDim.y
+  const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int stride = 4 * gridDim.y;
+  const int r0 = neuron * rpn;
+  const int r1 = r0 + rpn < rows ? r0 + rpn : rows;
+  if (r0 + wave >= r1) return;
+  const float* kr = keys + (long)neuron * k * A;
+  const int ne = (A + 63) / 64;
+  float wv[kAttMaxE], kv[kAttMaxK][kAttMaxE];
+  int av[kAttMaxE];
+#pragma unroll
+  for (int e = 0; e < kAttMaxE; ++e) {
+    const int a = lane + 64 * e;
+    const bool ok = a < A;
+    av[e] = ok ? a : 0;
+    wv[e] = ok ? w[a] : 0.f;  // (a lane past A adds w * tanh = 0 * finite)
+  }
+#pragma unroll
+  for (int j = 0; j < kAttMaxK; ++j)
+#pragma unroll
+    for (int e = 0; e < kAttMaxE; ++e)
+      kv[j][e] = (j < k && e < ne) ? kr[(long)j * A + av[e]] : 0.f;
+  const float b0 = b[0];
+  for (int r = r0 + wave; r < r1; r += stride) {
+    const float* qr = q + (long)r * A;
+    float qv[kAttMaxE];
+#pragma unroll
+    for (int e = 0; e < kAttMaxE; ++e) qv[e] = e < ne ? qr[av[e]] : 0.f;
+    float t[kAttMaxK];
+#pragma unroll
+    for (int j = 0; j < kAttMaxK; ++j) {
+      float s = 0.f;
+      if (j < k) {
+#pragma unroll
+        for (int e = 0; e < kAttMaxE; ++e)
+          if (e < ne) s += wv[e] * tanh_exp2(qv[e] + kv[j][e]);
+      }
+      t[j] = s;
+    }
+    // lanes whose bit X is clear keep the lower half of the live values, the others the upper
+#pragma unroll
+    for (int n = kAttMaxK, X = 32; n > 1; n >>= 1, X >>= 1) {
+      const bool hi = (lane & X) != 0;
+#pragma unroll
+      for (int i = 0; i < n / 2; ++i) {
+        const float recv = __shfl_xor(hi ? t[i] : t[i + n / 2], X);
+        t[i] = (hi ? t[i + n / 2] : t[i]) + recv;
+      }
+    }
+    float s = t[0] + __shfl_xor(t[0], 2);
+    s += __shfl_xor(s, 1);
+    s += b0;
+    const int j = lane >> 2;  // (32 -> 8, 16 -> 4, 8 -> 2, 4 -> 1)
+    const bool valid = j < k;
+    float mx = valid ? s : -INFINITY;
+#pragma unroll
+    for (int X = 4; X < 64; X <<= 1) mx = fmaxf(mx, __shfl_xor(mx, X));
+    const bool writer = valid && (lane & 3) == 0;
+    const float ev = writer ? expf(s - mx) : 0.f;
+    float sum = ev;
+#pragma unroll
+    for (int X = 4; X < 64; X <<= 1) sum += __shfl_xor(sum, X);
+    if (writer) att[(long)r * k + j] = ev / sum;
+  }
+}
+
+static void launch_attend(const float* q, const float* keys, const float* w, const float* b,
+                          int rows, int rpn, int k, int A, float* att, hipStream_t s) {
+  // MILAN_ATTEND_FAST=0: libm tanhf (A/B timing)
+  static const bool fast = !(getenv("MILAN_ATTEND_FAST") && atoi(getenv("MILAN_ATTEND_FAST")) == 0);
+  if (fast && k <= kAttMaxK && A <= 64 * kAttMaxE) {
+    // enough waves to fill the chip (>= 8 per CU), each with as many rows as that leaves
+    const int neurons = (rows + rpn - 1) / rpn;
+    int rs = (4096 + neurons * 4 - 1) / (neurons * 4);
+    const int rs_max = (rpn + 3) / 4;
+    rs = rs < 1 ? 1 : (rs > rs_max ? rs_max : rs);
+    hipLaunchKernelGGL(attend16_kernel, dim3(neurons, rs), dim3(256), 0, s, q, keys, w, b, rows,
+                       rpn, k, A, att);
+  } else {
+    hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, q, keys, w, b,
+                       rows, rpn, k, A, att);
+  }
+}
+
 // ctx[r][f] = sum_k att[r][k] * features[neuron][k][f]   (decoders.py:613)
 // One workgroup per (neuron, 1024-column slice): each thread keeps its float4
 // column of the neuron's k feature rows in registers and walks the neuron's rpn
@@ -1329,8 +1432,7 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
       return g;
     };
     MILAN_TRY(launch_gemm(split_lin(c->q2h, b->q, A, EPI_BIAS, nullptr, 0), s));
-    hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, b->q,
-                       keys, c->att_w, c->att_b, rows, rpn, k, A, b->att);
+    launch_attend(b->q, keys, c->att_w, c->att_b, rows, rpn, k, A, b->att, s);
     launch_context(b->att, features, rows, rpn, k, F, b->ctx, s);
     {
       GemmArgs g = split_lin(c->gate, xs + E, ldx, EPI_BIAS_SIGMUL, b->ctx, F);
@@ -1370,8 +1472,7 @@ static int step_core(milan_ctx* c, const float* features, const float* keys,
     return 0;
   }
   MILAN_TRY(lin(c, h, H, c->q2h, b->q, A, rows, EPI_BIAS, s));
-  hipLaunchKernelGGL(attend_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, b->q,
-                     keys, c->att_w, c->att_b, rows, rpn, k, A, b->att);
+  launch_attend(b->q, keys, c->att_w, c->att_b, rows, rpn, k, A, b->att, s);
   launch_context(b->att, features, rows, rpn, k, F, b->ctx, s);
   // gated = sigmoid(W_g h + b_g) * ctx  -> x[:, E:]
   MILAN_TRY(lin(c, h, H, c->gate, b->x + E, ldx, rows, EPI_BIAS_SIGMUL, s, b->ctx, F));
