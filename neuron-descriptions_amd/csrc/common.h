@@ -185,6 +185,15 @@ struct StemArgs {
   int tiles_y, tiles_x;  // filled by the launcher
   int debug;             // timing experiments: 1 no MFMA, 2 no store phase, 4 no DMA, 8 no staging
   unsigned* status;      // filled by the launcher (status_word())
+  // uint8 images straight into the stem (round 5): when in_u8 != nullptr the kernel reads the
+  // NCHW bytes of its input tile itself and turns them into pixel-pair groups through `lut`
+  // (3 x 256 + 1 entries: hi | lo << 16 of the normalised value of byte v in channel c at
+  // c * 256 + v, entry 768 = 0 for the padding) -- bit for bit what preprocess_pairs_kernel
+  // writes, without the 32-bytes-per-pixel-pair tensor `in` (unused then)
+  const unsigned char* in_u8;
+  const unsigned* lut;
+  const int* order;      // batch slot -> image number (encoder.hip, MILAN_FUSE_SKIP_EMPTY) or nullptr
+  int W;
 };
 bool stem_fused_supported(int cout, int Kp);
 int launch_stem_fused(const StemArgs& a, hipStream_t s);
@@ -445,6 +454,7 @@ struct milan_ctx {
   float act_scale = 32.f;
   int act_scale_log2 = 5;
   float *bn1_scale_s = nullptr, *bn1_shift_s = nullptr;
+  unsigned* stem_lut = nullptr;  // byte -> split value table of the uint8 stem (StemArgs::lut), lazily
   // device status word (MILAN_STATUS_* bits, milan_status): ORed by the split epilogues when
   // a value hit the +-65504 clamp and by the input conversion when a pixel was not finite
   unsigned* status = nullptr;

@@ -585,6 +585,28 @@ __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups
   report_saturation(status, sat);
 }
 
+// The table of the uint8 stem (stem.hip, StemArgs::lut): entry c * 256 + v = the split value
+// (hi | lo << 16) preprocess_pairs_kernel<uint8_t> writes for byte v in channel c -- the same
+// operations, value by value -- and entry 768 = 0 for the zero padding.  96 threads x 8 values.
+__global__ void stem_lut_kernel(float m0, float m1, float m2, float s0, float s1, float s2,
+                                unsigned* __restrict__ lut) {
+#pragma clang fp contract(off)  // see preprocess_kernel
+  const float inv255 = (float)(1.0 / 255.0);
+  const int t = threadIdx.x;
+  if (t >= 96) { if (t == 96) lut[768] = 0u; return; }
+  const int ch = t >> 5, v0 = (t & 31) * 8;
+  const float m = ch == 0 ? m0 : (ch == 1 ? m1 : m2), sd = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (((float)(v0 + e) * inv255) - m) / sd;
+  f32x4_t hi, lo;
+  enc_split8(v, &hi, &lo);
+  const unsigned short* h = reinterpret_cast<const unsigned short*>(&hi);
+  const unsigned short* l = reinterpret_cast<const unsigned short*>(&lo);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lut[ch * 256 + v0 + e] = (unsigned)h[e] | ((unsigned)l[e] << 16);
+}
+
 // Same, 8 channels per thread, output in split-f16 format (gemm.hip).
 __global__ void bn_relu_maxpool_split_kernel(const float* __restrict__ x, int n,
                                              int H, int W, int C, int Ho, int Wo,
@@ -1132,8 +1154,27 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   const bool pair_stem = split && c->stem_pair.ws != nullptr;
   const int G = (W + 2) / 2;  // pixel-pair groups per image row
 
+  // the fused stem reads uint8 images itself (StemArgs::in_u8): no pixel-pair tensor
+  // (MILAN_STEM_U8=0: through preprocess_pairs_kernel, the same bits; A/B timing)
+  static const bool stem_u8_on = !(getenv("MILAN_STEM_U8") && atoi(getenv("MILAN_STEM_U8")) == 0);
+  float norm_max = 0.f;  // largest normalised pixel magnitude: the table must not saturate
+  for (int ch = 0; ch < 3; ++ch) {
+    const float a0 = fabsf((0.f - c->mean[ch]) / c->stdv[ch]), a1 = fabsf((1.f - c->mean[ch]) / c->stdv[ch]);
+    norm_max = fmaxf(norm_max, fmaxf(a0, a1));
+  }
+  const bool stem_u8 = stem_u8_on && pair_stem && !spatial && image_dtype == MILAN_DTYPE_U8 &&
+                       (c->fusion & MILAN_FUSE_STEM) && norm_max < 60000.f && W % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(images) & 3) == 0 &&
+                       stem_fused_supported(c->stem_pair.cout, c->stem_pair.Kp);
+  if (stem_u8) {
+    if (c->stem_lut == nullptr) MILAN_TRY(dev_alloc(c, (void**)&c->stem_lut, sizeof(unsigned) * 772));
+    hipLaunchKernelGGL(stem_lut_kernel, dim3(1), dim3(128), 0, s, c->mean[0], c->mean[1], c->mean[2],
+                       c->stdv[0], c->stdv[1], c->stdv[2], c->stem_lut);
+    MILAN_CHECK_HIP(hipGetLastError());
+  }
+
   // 2. images -> normalised NHWC4 (fp32 stem) or pixel-pair groups (split stem)
-  {
+  if (!stem_u8) {
     const long np = pair_stem ? (long)n * H * G : (long)n * H * W;
     const int blocks = (int)((np + 255) / 256 < 8192 ? (np + 255) / 256 : 8192);
     const float m0 = c->mean[0], m1 = c->mean[1], m2 = c->mean[2];
@@ -1210,6 +1251,10 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       // tensor is only materialised where the level-0 pooling will read it
       StemArgs sa{};
       sa.in = pl.in4; sa.ws = c->stem_pair.ws; sa.bias = c->stem_pair.bias;
+      if (stem_u8) {
+        sa.in = nullptr; sa.in_u8 = (const unsigned char*)images; sa.lut = c->stem_lut;
+        sa.order = order; sa.W = W;
+      }
       sa.acc_scale = c->stem_pair.ws_inv;
       sa.scale = c->bn1_scale_s; sa.shift = c->bn1_shift_s;  // (activation scale)
       sa.raw = spatial ? nullptr : pl.raw; sa.y = pl.x0;

@@ -25,6 +25,7 @@
 // outputs are bitwise those of the three launches (tests/test_gpu_stem.py).
 #include "common.h"
 
+#include <cstdint>
 #include <cstdlib>
 
 namespace milan {
@@ -80,7 +81,7 @@ __device__ inline void stem_split8(const float* v, f32x4* hi_out, f32x4* lo_out,
 
 }  // namespace
 
-template <int PR, int PC, int NW>
+template <int PR, int PC, int NW, bool U8>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(StemArgs a) {
   // roundings as written (the unfused path rounds acc * scale before the bias add
   // because an LDS round trip sits between them); the one fused multiply-add of the
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
   constexpr int kMBW = T::kMBW;
   extern __shared__ __attribute__((aligned(16))) char stem_smem[];
   float* stg = reinterpret_cast<float*>(stem_smem + 2 * kInBytes);  // [32 kMB][kSRow]
+  // U8: the byte -> (hi, lo) table behind the staging tile (kLutWords words)
+  unsigned* lut = reinterpret_cast<unsigned*>(stem_smem + T::kLds);
   float sat = 0.f;  // (common.h: saturation of the split clamp is loud)
 
   const int tid = threadIdx.x;
@@ -156,6 +159,60 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
     }
   };
 
+  // ---- U8: thread t < kInR * kInC / 2 builds the pixel-pair groups 2j, 2j + 1 of tile row
+  // t / (kInC / 2): their four pixels X0 + 4j .. + 3 (X0 = 3 mod 4) are byte 3 of one aligned
+  // dword of the image row and bytes 0..2 of the next -- 6 dword loads (2 x 3 planes), 12 table
+  // look-ups, the hi pieces at g, the lo pieces at kPieces + g (the layout the DMA produces).
+  // Needs W % 4 == 0 and a 4-byte aligned image pointer (launcher).
+  static_assert(kInC % 2 == 0, "pixel-pair groups come in pairs");
+  constexpr int kHalfC = kInC / 2;
+  const int u_row = tid / kHalfC, u_j = tid - u_row * kHalfC;
+  const bool u_ok = U8 && tid < T::kInR * kHalfC;
+  // ub[0..2] = dword A of planes R, G, B, ub[3..5] = dword B, ub[6] = validity (bit 0: A, bit 1: B)
+  auto fetch = [&](int img, int ta, int tb, unsigned (&ub)[7]) {
+    const int iy0 = 2 * (2 * kPoolR * ta - 1) - 3;
+    const int xa = 4 * kPoolC * tb - 8 + 4 * u_j;  // first pixel of dword A; pixel P0 = xa + 3
+    const int iy = iy0 + u_row;
+    const long hw = (long)a.H * a.W;
+    const bool row_ok = u_ok && iy >= 0 && iy < a.H;
+    const bool ok_a = row_ok && xa >= 0 && xa < a.W, ok_b = row_ok && xa + 4 >= 0 && xa + 4 < a.W;
+    const unsigned char* p = a.in_u8 + (long)(a.order ? a.order[img] : img) * 3 * hw + (long)iy * a.W + xa;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      ub[ch] = ok_a ? *reinterpret_cast<const unsigned*>(p + ch * hw) : 0u;
+      ub[3 + ch] = ok_b ? *reinterpret_cast<const unsigned*>(p + ch * hw + 4) : 0u;
+    }
+    ub[6] = (ok_a ? 1u : 0u) | (ok_b ? 2u : 0u);
+  };
+  auto convert = [&](const unsigned (&ub)[7], int buf) {
+    if (!u_ok) return;
+    char* dst = stem_smem + buf * kInBytes;
+    const bool ok_a = ub[6] & 1u, ok_b = ub[6] & 2u;
+    unsigned e[4][3];  // table entries of pixels P0..P3, channels R G B (768 = 0.0: outside the image)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      e[0][ch] = lut[ok_a ? ch * 256u + (ub[ch] >> 24) : 768u];
+      e[1][ch] = lut[ok_b ? ch * 256u + (ub[3 + ch] & 255u) : 768u];
+      e[2][ch] = lut[ok_b ? ch * 256u + ((ub[3 + ch] >> 8) & 255u) : 768u];
+      e[3][ch] = lut[ok_b ? ch * 256u + ((ub[3 + ch] >> 16) & 255u) : 768u];
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      // group = (R0 G0 B0 0 R1 G1 B1 0): halfword j of a piece = value j
+      const unsigned* p0 = e[2 * q];
+      const unsigned* p1 = e[2 * q + 1];
+      u32x4 hi, lo;
+      hi[0] = (p0[0] & 0xffffu) | (p0[1] << 16); hi[1] = p0[2] & 0xffffu;
+      hi[2] = (p1[0] & 0xffffu) | (p1[1] << 16); hi[3] = p1[2] & 0xffffu;
+      lo[0] = (p0[0] >> 16) | (p0[1] & 0xffff0000u); lo[1] = p0[2] >> 16;
+      lo[2] = (p1[0] >> 16) | (p1[1] & 0xffff0000u); lo[3] = p1[2] >> 16;
+      const int g = u_row * kInC + 2 * u_j + q;
+      *reinterpret_cast<u32x4*>(dst + g * 16) = hi;
+      *reinterpret_cast<u32x4*>(dst + (kPieces + g) * 16) = lo;
+    }
+  };
+
   // ---- A fragment addresses: pixel t = 32 (2 mp + i) + lane % 32 of the tile ----
   int abase[kMBW];
 #pragma unroll
@@ -189,15 +246,27 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
 
   int img, ta, tb;
   bool have = decode(&img, &ta, &tb);
-  if (have) issue(img, ta, tb, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  unsigned ub[7];
+  if constexpr (U8) {
+    for (int i = tid; i < 769; i += NW * 64) lut[i] = a.lut[i];
+    __syncthreads();
+    if (have) {
+      fetch(img, ta, tb, ub);
+      convert(ub, 0);
+    }
+    __syncthreads();
+  } else {
+    if (have) issue(img, ta, tb, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
   for (int it = 0; have; ++it) {
     const int buf = it & 1;
     int nimg, nta, ntb;
     const bool nhave = decode(&nimg, &nta, &ntb);
-    if (nhave && !STEM_ABLATE(4)) issue(nimg, nta, ntb, buf ^ 1);
+    if constexpr (!U8)
+      if (nhave && !STEM_ABLATE(4)) issue(nimg, nta, ntb, buf ^ 1);
 
     // ---- conv1 on the matrix cores ----
     f32x16 acc[kMBW], accx[kMBW];
@@ -238,6 +307,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
     // next tile's input has had the whole MFMA loop to land
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // U8: the next tile's bytes travel under the store phase and are converted after it
+    if constexpr (U8)
+      if (nhave) fetch(nimg, nta, ntb, ub);
 
     // ---- (a) raw conv1 rows for the level-0 masked pooling ----
     const int cr0 = 2 * kPoolR * ta - 1, cc0 = 2 * kPoolC * tb - 1;
@@ -303,6 +375,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
         *reinterpret_cast<f32x4*>(d + 4) = lo4;
       }
     }
+    if constexpr (U8) {
+      if (nhave) convert(ub, buf ^ 1);
+      __syncthreads();  // (the DMA form publishes the next tile at the barrier after the staging)
+    }
     have = nhave; img = nimg; ta = nta; tb = ntb;
   }
   report_saturation(a.status, sat);
@@ -310,22 +386,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
 
 bool stem_fused_supported(int cout, int Kp) { return cout == 64 && Kp == 224; }
 
-template <int PR, int PC, int NW>
+template <int PR, int PC, int NW, bool U8>
 static int launch_stem_cfg(StemArgs a, int cus, hipStream_t s) {
   using T = StemTile<PR, PC, NW>;
   a.tiles_y = (a.hp + PR - 1) / PR;
   a.tiles_x = (a.wp + PC - 1) / PC;
-  auto kern = stem_fused_kernel<PR, PC, NW>;
-  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)T::kLds));
+  auto kern = stem_fused_kernel<PR, PC, NW, U8>;
+  const size_t lds = T::kLds + (U8 ? 772 * sizeof(unsigned) : 0);
+  MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   // persistent: one workgroup per CU (8 waves) or two (4 waves each)
-  hipLaunchKernelGGL(kern, dim3(cus * (NW == 8 ? 1 : 2)), dim3(NW * 64), T::kLds, s, a);
+  hipLaunchKernelGGL(kern, dim3(cus * (NW == 8 ? 1 : 2)), dim3(NW * 64), lds, s, a);
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_stem_fused(const StemArgs& a, hipStream_t s) {
-  MILAN_REQUIRE(a.n > 0 && a.H > 0 && a.G > 0 && a.in && a.ws && a.y && a.scale &&
-                    a.shift && a.zero,
+  MILAN_REQUIRE(a.in_u8 == nullptr || (a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in_u8) & 3) == 0),
+                MILAN_ERR_ARG, "stem: uint8 input needs W %% 4 == 0 and a 4-byte aligned pointer");
+  MILAN_REQUIRE(a.n > 0 && a.H > 0 && a.G > 0 && (a.in || (a.in_u8 && a.lut && a.W > 0)) && a.ws &&
+                    a.y && a.scale && a.shift && a.zero,
                 MILAN_ERR_ARG, "stem: missing operand");
   int cus = 0;
   MILAN_TRY(device_cus8(&cus));
@@ -336,17 +415,18 @@ int launch_stem_fused(const StemArgs& a, hipStream_t s) {
   const double px1 = (double)a.n * a.h1 * a.w1, pxp = (double)a.n * a.hp * a.wp;
   void* rec = gemm_profile_begin(
       2.0 * px1 * 64 * 147,
-      32.0 * a.n * a.H * a.G + (a.raw ? 256.0 * px1 : 0.0) + 256.0 * pxp, s);
+      (a.in_u8 ? 3.0 * a.n * a.H * a.W : 32.0 * a.n * a.H * a.G) + (a.raw ? 256.0 * px1 : 0.0) +
+          256.0 * pxp, s);
   profile_tag_kernel(MILAN_KERNEL_STEM);
   int r;
 #if MILAN_EXPERIMENTS
   // MILAN_STEM_TILE=0: 3 x 8 pooled pixels per 4-wave workgroup, two per CU (measured
   // slower: 5.8 against 5.3 ms per 256 neurons, profiles/r3_experiments.txt)
   static const int variant = getenv("MILAN_STEM_TILE") ? atoi(getenv("MILAN_STEM_TILE")) : 1;
-  if (variant == 0) r = launch_stem_cfg<3, 8, 4>(aa, cus, s);
+  if (variant == 0 && !aa.in_u8) r = launch_stem_cfg<3, 8, 4, false>(aa, cus, s);
   else
 #endif
-  r = launch_stem_cfg<7, 8, 8>(aa, cus, s);
+  r = aa.in_u8 ? launch_stem_cfg<7, 8, 8, true>(aa, cus, s) : launch_stem_cfg<7, 8, 8, false>(aa, cus, s);
   gemm_profile_end(rec, s);
   return r;
 }

@@ -11,7 +11,7 @@ for v in "$@"; do
 import json
 d = json.load(open("/tmp/ab.json"))
 st = {s["stage"]: s for s in d["roofline"]["stages"]}
-keys = ("encoder.layer1", "encoder.layer2", "encoder.layer3", "encoder.layer4", "decoder.search", "decoder.lm_rerank")
+keys = ("encoder.input", "encoder.stem", "encoder.layer1", "encoder.layer2", "encoder.layer3", "encoder.layer4", "decoder.search", "decoder.lm_rerank")
 print("$var=$v", round(d["value"], 1), d["config"].get("gathered_tokens_sha256", "")[:12],
       " ".join("%s %.2f" % (k.split(".")[1], st[k]["ms_per_step"]) for k in keys))
 PY

@@ -50,7 +50,8 @@ PINNED = {
     'chain_kernelILi64ELi8ELb0ELi64ELb1': {'mfma': 72, 'lds_dma': 12, 'global_load_x4': 22, 'global_store_x4': 16, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 2, 4]},
     'chain_kernelILi64ELi8ELb0ELi0ELb0ELb0ELi128': {'mfma': 72, 'lds_dma': 12, 'global_load_x4': 32, 'global_store_x4': 24, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 1, 2, 12]},
     'conv3_p64_kernel': {'mfma': 162, 'lds_dma': 20, 'global_load_x4': 36, 'global_store_x4': 4, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 5]},
-    'stem_fused_kernelILi7ELi8ELi8': {'mfma': 84, 'lds_dma': 6, 'global_load_x4': 33, 'global_store_x4': 10, 'barriers': 3, 'scratch': 6, 'vmcnt': [0]},
+    'stem_fused_kernelILi7ELi8ELi8ELb0': {'mfma': 84, 'lds_dma': 6, 'global_load_x4': 33, 'global_store_x4': 10, 'barriers': 3, 'scratch': 6, 'vmcnt': [0]},
+    'stem_fused_kernelILi7ELi8ELi8ELb1': {'mfma': 84, 'lds_dma': 0, 'global_load_x4': 33, 'global_store_x4': 10, 'barriers': 5, 'scratch': 8, 'vmcnt': [0]},
 }
 
 
