@@ -9,7 +9,11 @@
 //   * a workgroup owns an 8 x 14 tile of output pixels; the 10 x 16 input pixels
 //     behind it are staged in LDS ONCE (global_load_lds, whole 256-byte pixels, a
 //     three-deep ring of tiles) and the A fragments of all nine taps are read
-//     straight from that tile (16-byte slots of a pixel XOR-swizzled by its column);
+//     straight from that tile (16-byte slots of a pixel XOR-swizzled by 14 row + column:
+//     lane l of a fragment read is output pixel 14 pr + pc = 32 block + l, so for every
+//     tap the sixteen lanes of a ds_read_b128 group carry sixteen different keys --
+//     round 5; keyed by the column alone two lanes of every group met in a slot, 41 % of
+//     the kernel's LDS cycles);
 //   * the 64 x 576 weights never touch LDS: wave (nb, kh) keeps the B fragments of
 //     output channels 32 nb .. 32 nb + 31 for HALF of K (18 of the 36 k-slabs, 144
 //     registers) for the whole kernel;
@@ -71,12 +75,12 @@ __device__ __forceinline__ void c3_mfma(const char* buf, int pbase, int pc, int 
     const int sg = KH * kHalfSlabs + s;
     const int tap = sg >> 2, kh = tap / 3, kw = tap - kh * 3;
     const int jh = ((4 * sg) & 15) + 2 * half;  // 16-byte slot of the hi piece
-    const int x = pc + kw;                      // input column = swizzle key
+    const int x = pc + kTC * kh + kw;           // swizzle key of input pixel (pr + kh, pc + kw)
     const char* p = buf + pbase + (kh * kIC + kw) * 256;
     asm volatile("ds_read_b128 %0, %1"
-                 : "=v"(ah[b3]) : "v"((LDS_AS const char*)(p + ((jh ^ x) << 4))) : "memory");
+                 : "=v"(ah[b3]) : "v"((LDS_AS const char*)(p + (((jh ^ x) & 15) << 4))) : "memory");
     asm volatile("ds_read_b128 %0, %1"
-                 : "=v"(al[b3]) : "v"((LDS_AS const char*)(p + (((jh + 1) ^ x) << 4))) : "memory");
+                 : "=v"(al[b3]) : "v"((LDS_AS const char*)(p + ((((jh + 1) ^ x) & 15) << 4))) : "memory");
   };
   // two slabs ahead: a wave alone on its SIMD (its partner is in the epilogue) must
   // cover the whole LDS latency by itself
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
     t = t < kTR * kTC ? t : kTR * kTC - 1;
     const int pr = t / kTC, pc = t - pr * kTC;
     pbase[b] = (pr * kIC + pc) * 256;
-    pcol[b] = pc;
+    pcol[b] = kTC * pr + pc;  // (c3_mfma adds the tap's 14 kh + kw: key = 14 row + column)
   }
 
   // ---- tile sequence (XCD x walks images x, x + 8, ...; see stem.hip) ----
@@ -157,9 +161,8 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
 
   // DMA batch g = tile g / 2, rows 5 (g % 2) .. + 4 of the 10-row input tile: loader wave
   // `pair`, instruction k moves row 5 (g % 2) + k, columns 4 pair .. 4 pair + 3
-  // (4 pixels x 16 slots); LDS slot jj of pixel (r, c) holds memory piece jj ^ c
+  // (4 pixels x 16 slots); LDS slot jj of pixel (r, c) holds memory piece jj ^ (14 r + c)
   const int ld_c = 4 * pair + (lane >> 4);
-  const int ld_j = ((lane & 15) ^ ld_c) * 4;  // floats
   auto issue_batch = [&](int g) -> bool {
     const int i = g >> 1;
     int img, ty, tx;
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
       const int r = (g & 1) * kBatch + k;
       const int iy = ty * kTR - 1 + r;
       const bool ok = xok && iy >= 0 && iy < a.h;
+      const int ld_j = ((lane ^ (kTC * r + ld_c)) & 15) * 4;  // floats
       const float* src = ok ? a.in + (((long)img * a.h + iy) * a.w + ix) * 64 + ld_j : a.zero;
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src,
                                        (LDS_AS void*)(dst + (r * kIC + 4 * pair) * 256), 16,

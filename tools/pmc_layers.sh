@@ -4,7 +4,7 @@
 cd /root/repo
 for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmcl_$c
-  timeout 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmcl_$c -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 2>&1 | tail -1 | cut -c1-80
+  timeout 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmcl_$c -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 --live-traffic 0 2>&1 | tail -1 | cut -c1-80
   cd /root/repo
   f=$(find /tmp/pmcl_$c -name "*.db" | head -1)
   python - "$f" $c > gpurun_out/pmc_dispatch_$c.txt <<'PY'

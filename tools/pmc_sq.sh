@@ -4,7 +4,7 @@
 out=$1; ctrs=$2
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc
-timeout 500 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 2>&1 | tail -1 | cut -c1-120
+timeout 500 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc -o p -- python /root/repo/bench.py --chunk 256 --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 --live-traffic 0 2>&1 | tail -1 | cut -c1-120
 cd /root/repo
 f=$(find /tmp/pmc -name "*.db" | head -1)
 python - > gpurun_out/${out}_pmc.txt <<PY
