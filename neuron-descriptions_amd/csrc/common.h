@@ -53,6 +53,10 @@ enum Epilogue : int {
                           // gate-interleaved per 16 units ([i16 f16 g16 o16] per 64):
                           // C = h' (ldc), C2 = c' (ldc), aux = c (ldaux), Cs =
                           // optional split-format copy of h' (ldc); N = 4 H
+  EPI_LSE = 7,            // x = acc + bias is NOT written: per row m and 64-column block cb,
+                          // C[m * ldc + 2 cb] = { max x, sum exp(x - max) } (ldc = 2 ceil(N / 64)),
+                          // and lse_x[m] = x[m][lse_tgt[m * lse_tgt_stride]] -- what a log-softmax
+                          // read at one target column needs (the LM's rerank pass, decoder.hip)
 };
 
 // C[M][N] (row stride ldc) = epi( A (*) W^T + bias ), fp32 MFMA, exact f32.
@@ -120,6 +124,9 @@ struct GemmArgs {
                       // asks for the KH * KW shifted copies of a slice in CONSECUTIVE k-tile pairs:
                       // they hit L2 instead of crossing the fabric once per tap (gemm.hip, TAPI)
   int tap_inner;      // filled by the launcher: this launch runs in that order
+  const long long* lse_tgt;  // EPI_LSE: target column of row m at lse_tgt[m * lse_tgt_stride]
+  long lse_tgt_stride;
+  float* lse_x;              // EPI_LSE: [M] the target column's x
 };
 
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2, OUT_F16 = 3 };

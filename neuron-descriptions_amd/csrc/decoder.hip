@@ -1149,6 +1149,34 @@ __global__ __launch_bounds__(256) void lm_accumulate_kernel(
   }
 }
 
+// The same from the statistics the vocabulary GEMM's EPI_LSE epilogue leaves (gemm.hip): per
+// row and 64-column block {max, sum exp(x - max)}, and the target column's x -- the 4 V bytes
+// per row of logits are neither written nor read back (1.28 GB per step at 32 000 rows).
+// logsumexp = M + log(sum_b s_b exp(m_b - M)); one wave per row.
+__global__ __launch_bounds__(256) void lm_accumulate_lse_kernel(
+    const float* __restrict__ part, int nb, const float* __restrict__ xt, int rows,
+    const int64_t* __restrict__ seqs, long lds, int t, const int32_t* __restrict__ seq_len,
+    int len_div, int stop, float* __restrict__ alive, float* __restrict__ total) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* p = part + (long)r * nb * 2;
+  float mx = -INFINITY;
+  for (int b = lane; b < nb; b += 64) mx = fmaxf(mx, p[2 * b]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float s = 0.f;
+  for (int b = lane; b < nb; b += 64) s += p[2 * b + 1] * expf(p[2 * b] - mx);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    const int64_t in = seqs[(long)r * lds + t];
+    const bool valid = seq_len == nullptr || (t + 1) < seq_len[r / len_div];
+    const float a = t == 0 ? 1.f : alive[r];
+    float tot = t == 0 ? 0.f : total[r];
+    if (valid) tot += a * ((xt[r] - mx) - logf(s));
+    total[r] = tot;
+    alive[r] = a * (in != stop ? 1.f : 0.f);
+  }
+}
+
 // seqs[r] = [start, beam_tokens[r][0..T)]
 __global__ void build_lm_seqs_kernel(const int64_t* __restrict__ beam_tokens,
                                      long rows, int T, int64_t start,
@@ -1585,9 +1613,12 @@ static bool lm_split_ok(const milan_ctx* c, int rows) {
   return true;
 }
 
+// lse_tgt != nullptr: the vocabulary GEMM leaves log-sum-exp statistics (EPI_LSE) in `logits`
+// ((rows, 2 nb) floats, then (rows) target values) instead of the logits themselves
 static int lm_step_split(milan_ctx* c, const int64_t* tok, int rows, LmState& st,
                          LmState& nx, float* hs, int cur, float* logits,
-                         hipStream_t s) {
+                         hipStream_t s, const int64_t* lse_tgt = nullptr,
+                         long lse_tgt_stride = 0) {
   const milan_dims& d = c->d;
   const int Hl = d.lm_hidden_size, El = d.lm_embedding_size, V = d.vocab_size;
   float* emb_s = c->scratch;
@@ -1619,6 +1650,14 @@ static int lm_step_split(milan_ctx* c, const int64_t* tok, int rows, LmState& st
                            c->lm_out.n, c->lm_out.k, EPI_BIAS, c->zero);
   g.a_split = 1;
   g.acc_scale = c->lm_out.ws_inv;
+  if (lse_tgt) {
+    const int nb = (V + 63) / 64;
+    g.epilogue = EPI_LSE;
+    g.ldc = 2 * nb;
+    g.lse_tgt = reinterpret_cast<const long long*>(lse_tgt);
+    g.lse_tgt_stride = lse_tgt_stride;
+    g.lse_x = logits + (size_t)rows * 2 * nb;
+  }
   MILAN_TRY(launch_gemm(g, s));
   MILAN_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1643,6 +1682,9 @@ static int lm_score_impl(milan_ctx* c, const int64_t* seqs, int rows, int L,
   int cur = 0;
   // split hidden states live in the gate matrix, which the fused cell never writes
   const bool split = lm_split_ok(c, rows) && (long)rows == b->lm[0].rows;
+  // MILAN_LM_LSE=0: logits through HBM + lm_accumulate_kernel (A/B timing)
+  static const bool lse_on = !(getenv("MILAN_LM_LSE") && atoi(getenv("MILAN_LM_LSE")) == 0);
+  const bool lse = lse_on && d.vocab_size % 4 == 0 && d.vocab_size >= 256;
   if (split)
     MILAN_CHECK_HIP(hipMemsetAsync(
         b->lm_gates, 0,
@@ -1650,6 +1692,17 @@ static int lm_score_impl(milan_ctx* c, const int64_t* seqs, int rows, int L,
   for (int t = 0; t + 1 < L; ++t) {
     hipLaunchKernelGGL(gather_col_kernel, dim3(nblk(rows)), dim3(256), 0, s, seqs,
                        (long)rows, (long)L, t, b->tok);
+    if (split && lse) {
+      // the vocabulary GEMM leaves the log-softmax statistics of every row, not the logits
+      const int nb = (d.vocab_size + 63) / 64;
+      MILAN_TRY(lm_step_split(c, b->tok, rows, b->lm[cur], b->lm[cur ^ 1],
+                              b->lm_gates, cur, b->lm_logits, s, seqs + t + 1, (long)L));
+      hipLaunchKernelGGL(lm_accumulate_lse_kernel, dim3((rows + 3) / 4), dim3(256), 0, s,
+                         b->lm_logits, nb, b->lm_logits + (size_t)rows * 2 * nb, rows, seqs,
+                         (long)L, t, seq_len, len_div, d.stop_index, b->lm_alive, total);
+      cur ^= 1;
+      continue;
+    }
     if (split)
       MILAN_TRY(lm_step_split(c, b->tok, rows, b->lm[cur], b->lm[cur ^ 1],
                               b->lm_gates, cur, b->lm_logits, s));

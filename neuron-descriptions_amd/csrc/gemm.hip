@@ -121,6 +121,27 @@ __device__ inline void join8(f32x4 hi, f32x4 lo, float* v) { join8_exact(hi, lo,
 // epilogue shared by all tile configurations (wave tile = TM x TN MFMA tiles,
 // rows row0.., columns col0..; TN == 2, i.e. 64 columns per wave)
 // ---------------------------------------------------------------------------
+// max / sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, mirror
+// inside each half row, mirror of the row -- four VALU instructions (a ds_bpermute butterfly is
+// four dependent LDS round trips).  s_nop: a DPP operand written by the previous VALU instruction
+// needs two wait states, which the assembler does not insert inside inline asm.
+__device__ __forceinline__ float row16_max(float x) {
+  asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+               : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ float row16_sum(float x) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+               : "+v"(x));
+  return x;
+}
+
 template <int TM, int TN, bool SWZ64 = false>
 __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
                                              f32x16 (&acc)[TM][TN], float* smem,
@@ -203,6 +224,59 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
             for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
           }
           *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
+        }
+      }
+    }
+  };
+
+  // (1b) EPI_LSE: the row statistics of a log-softmax instead of the 4 N bytes per row of x.
+  // The 16 lanes that share a staged row cover this wave's 64 columns: maximum and sum of
+  // exponentials are reduced over them (xor 1, 2, 4, 8 stays inside the 16-lane group).
+  auto epilogue_lse = [&]() {
+    const int col4 = (lane & 15) * 4;
+    const int n = col0 + col4;
+    const bool n_ok = n < g.N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+    const int cb = col0 >> 6;
+    // target columns one row-tile ahead of the stores (C and lse_tgt are not provably distinct:
+    // a load behind a store would wait for it -- see epilogue_split8)
+    int tg[2][8];
+    auto load_tgt = [&](int i, int (&t)[8]) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = row0 + i * 32 + it * 4 + (lane >> 4);
+        t[it] = m < g.M ? (int)g.lse_tgt[(long)m * g.lse_tgt_stride] : -1;
+      }
+    };
+    load_tgt(0, tg[0]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i + 1 < TM) load_tgt(i + 1, tg[(i + 1) & 1]);
+      to_stage(i);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = row0 + i * 32 + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage_out + row * SROW + sw(row, col4));
+        v += bias4;
+        const bool ok = m < g.M && n_ok;
+        float mx = ok ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
+        mx = row16_max(mx);
+        // (exp on v_exp_f32: x - mx <= 0, the error of the sum is that of its largest terms)
+        float e = ok ? (__expf(v[0] - mx) + __expf(v[1] - mx)) + (__expf(v[2] - mx) + __expf(v[3] - mx)) : 0.f;
+        e = row16_sum(e);
+        if (m < g.M && col0 < g.N) {
+          if ((lane & 15) == 0) {
+            float* d = g.C + (long)m * g.ldc + 2 * cb;
+            d[0] = mx;
+            d[1] = e;
+          }
+          const int tgt = tg[i & 1][it];
+          if (n_ok && tgt >= n && tgt < n + 4) {
+            const int q = tgt - n;
+            g.lse_x[m] = q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : v[3]));
+          }
         }
       }
     }
@@ -475,6 +549,8 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
   };
   if (g.epilogue == EPI_LSTM) {
     epilogue_lstm();
+  } else if (g.epilogue == EPI_LSE) {
+    epilogue_lse();
   } else if (g.out_mode == OUT_F16) {
     switch (g.epilogue) {
       case EPI_BIAS_RELU: epilogue_f16(std::integral_constant<int, EPI_BIAS_RELU>{}); break;
@@ -2449,6 +2525,7 @@ static double gemm_algorithmic_bytes(const GemmArgs& g) {
     c = M * H * (g.Cs ? 3.0 : 2.0);
     aux = M * H;
   }
+  if (g.epilogue == EPI_LSE) c = M * ((double)g.ldc + 1.0);  // statistics + the target's x
   if (g.f16) { c *= 0.5; aux *= 0.5; }   // (2-byte outputs; the K side is already in 4-byte units)
   return 4.0 * (a + (double)g.N * g.Kp + c + aux);
 }
@@ -2843,7 +2920,14 @@ static int launch_gemm_impl(GemmArgs g, hipStream_t s) {
 #endif
   }
   // pick the epilogue form
-  if (g.epilogue == EPI_LSTM) {
+  if (g.epilogue == EPI_LSE) {
+    MILAN_REQUIRE(!g.out_split && !g.aux_split && !g.f16 && g.aux == nullptr && g.N % 4 == 0 &&
+                      g.ldc == 2 * ((g.N + 63) / 64) && g.C && g.lse_tgt && g.lse_x &&
+                      (g.bias == nullptr || aligned16(g.bias)),
+                  MILAN_ERR_SHAPE, "gemm: bad log-sum-exp epilogue geometry (N=%d ldc=%d)", g.N,
+                  g.ldc);
+    g.out_mode = OUT_VEC4;
+  } else if (g.epilogue == EPI_LSTM) {
     MILAN_REQUIRE(!g.out_split && !g.aux_split && g.N % 64 == 0 && g.ldc % 8 == 0 &&
                       g.ldaux % 4 == 0 && g.C && g.C2 && g.aux && aligned16(g.C) &&
                       aligned16(g.C2) && aligned16(g.aux) &&
