@@ -155,6 +155,7 @@ void milan_destroy(milan_ctx* c) {
   for (auto& g : c->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->owned) (void)hipFree(p);
+  if (c->host_count) (void)hipHostFree(c->host_count);
   delete c;
 }
 

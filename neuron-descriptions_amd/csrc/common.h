@@ -462,6 +462,7 @@ struct milan_ctx {
   int act_scale_log2 = 5;
   float *bn1_scale_s = nullptr, *bn1_shift_s = nullptr;
   unsigned* stem_lut = nullptr;  // byte -> split value table of the uint8 stem (StemArgs::lut), lazily
+  int* host_count = nullptr;     // pinned host word for the encoder's 4-byte read-back (MILAN_FUSE_SKIP_EMPTY), lazily
   // device status word (MILAN_STATUS_* bits, milan_status): ORed by the split epilogues when
   // a value hit the +-65504 clamp and by the input conversion when a pixel was not finite
   unsigned* status = nullptr;

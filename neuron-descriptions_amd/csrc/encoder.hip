@@ -1127,9 +1127,11 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     hipLaunchKernelGGL(compact_images_kernel, dim3(1), dim3(1024), 0, s, pl.list_n, n_all,
                        pl.bbox, pl.order, pl.bbox_c, pl.count);
     MILAN_CHECK_HIP(hipGetLastError());
-    int live = n_all;
-    MILAN_CHECK_HIP(hipMemcpyAsync(&live, pl.count, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (c->host_count == nullptr)
+      MILAN_CHECK_HIP(hipHostMalloc((void**)&c->host_count, sizeof(int), hipHostMallocDefault));
+    MILAN_CHECK_HIP(hipMemcpyAsync(c->host_count, pl.count, sizeof(int), hipMemcpyDeviceToHost, s));
     MILAN_CHECK_HIP(hipStreamSynchronize(s));
+    const int live = *c->host_count;
     MILAN_REQUIRE(live >= 0 && live <= n_all, MILAN_ERR_STATE, "encode: image compaction failed");
     if (live < n_all) {
       MILAN_CHECK_HIP(hipMemsetAsync(features, 0, sizeof(float) * (size_t)n_all * c->d.feature_size, s));

@@ -78,8 +78,9 @@ class ChunkPrefetcher:
         main = torch.cuda.current_stream(self.device)
         done_events = [None] * self.depth  # compute finished reading slot
         dev = [None] * self.depth
-        for _ in range(self.n):
-            item = self._q.get()
+
+        def enqueue(item):
+            """H2D of one staged chunk on the copy stream -> (slot, images, masks, ready)."""
             if item is None:
                 raise self._error
             i, images, masks = item
@@ -96,6 +97,24 @@ class ChunkPrefetcher:
             d_im.record_stream(main)
             if d_mk is not None:
                 d_mk.record_stream(main)
+            return slot, d_im, d_mk, ready
+
+        ahead = None
+        for k in range(self.n):
+            cur = ahead if ahead is not None else enqueue(self._q.get())
+            ahead = None
+            # One-chunk lookahead on the COPY queue too: if chunk k+1 is already staged, its H2D
+            # is requested before chunk k is handed out.  A consumer that synchronises inside
+            # its call (the encoder's 4-byte read-back, MILAN_FUSE_SKIP_EMPTY) and then queues a
+            # result D2H would otherwise submit that D2H -- blocked until chunk k is computed --
+            # ahead of the next H2D, which then ran AFTER chunk k instead of under it (measured:
+            # 34 ms per 640-neuron chunk, tools/debug_host_loop.py).  Never waits for a slow fetch.
+            if k + 1 < self.n:
+                try:
+                    ahead = enqueue(self._q.get(timeout=0.002))
+                except queue.Empty:
+                    ahead = None
+            slot, d_im, d_mk, ready = cur
             main.wait_event(ready)
             yield d_im, d_mk
             ev = torch.cuda.Event()

@@ -3,7 +3,7 @@
 cd /root/repo
 for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$c
-  timeout 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p -- python /root/repo/bench.py --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 2>&1 | tail -1 | cut -c1-100
+  timeout 500 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p -- python /root/repo/bench.py --steps 1 --warmup 0 --also-f32-steps 0 --cpu-sample 0 --no-profile --from-host-steps 0 --other-configs 0 --fast-steps 0 --live-traffic 0 2>&1 | tail -1 | cut -c1-100
   cd /root/repo
   f=$(find /tmp/pmc_$c -name "*.db" | head -1)
   python - > gpurun_out/traffic_$c.txt <<PY
