@@ -299,6 +299,28 @@ class ClockPowerSampler:
                           'every 0.25 s during the timed region, rank 0\'s GPU'}
 
 
+def kernel_family(name):
+    """rocprofv3 kernel name -> the kernel-family key of `roofline.by_kernel`
+    (milan_profile_read_kernels): the ping-pong tile and its tap-inner form are ONE family."""
+    if 'igemm_split16_pp32_kernel' in name or 'pp32t_kernel<256>' in name:
+        return 'pp32_256'
+    if 'pp32n_kernel<128>' in name or 'pp32t_kernel<128>' in name:
+        return 'pp32_128'
+    if 'igemm_f16_pp32' in name:
+        return 'f16'
+    if 'chain3_kernel' in name:
+        return 'chain_wide'
+    if 'chain_kernel' in name:
+        return 'chain'
+    if 'stem_fused' in name:
+        return 'stem'
+    if 'conv3_p64' in name:
+        return 'conv3'
+    if 'igemm' in name:
+        return 'split_other'
+    return None
+
+
 def measure_traffic_live(args):
     """HBM bytes per launch of the dominant GEMM kernel, measured NOW: two child runs of
     this script (one step, same chunk, same precision) under `rocprofv3 --kernel-trace
@@ -341,22 +363,24 @@ def measure_traffic_live(args):
             q = ('select kernel_name, count(*), sum(value) from counters_collection '
                  'where counter_name = ? group by kernel_name')
             for name, launches, total in db.execute(q, (counter,)):
-                if any(k in name for k in ('igemm', 'chain_kernel', 'chain3_kernel', 'stem_fused', 'conv3_p64')):
-                    totals.setdefault(name, {})[counter] = (launches, total)
-    best = None
-    for name, t in totals.items():
+                fam = kernel_family(name)
+                if fam is not None:
+                    have = totals.setdefault(fam, {}).get(counter, (0, 0.0))
+                    totals[fam][counter] = (have[0] + launches, have[1] + total)
+    families = {}
+    for fam, t in totals.items():
         if 'FETCH_SIZE' not in t or 'WRITE_SIZE' not in t:
             continue
         launches = t['FETCH_SIZE'][0]
-        per_launch = (2 * t['FETCH_SIZE'][1] + t['WRITE_SIZE'][1]) * 1024 / launches
-        if best is None or per_launch * launches > best[1] * best[2]:
-            best = (name, per_launch, launches)
-    if best is None:
+        families[fam] = ((2 * t['FETCH_SIZE'][1] + t['WRITE_SIZE'][1]) * 1024 / launches,
+                         launches)
+    if not families:
         return None, 'no GEMM kernel found in the PMC databases'
-    return best[1], (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / '
-                     f'WRITE_SIZE (two child passes of one {args.chunk}-neuron step), '
-                     f'kernel with the most traffic = {best[0][:70]} ({best[2]} launches); '
-                     'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch')
+    # (the caller picks the family its HIP-event timing found dominant)
+    return families, (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / '
+                      f'WRITE_SIZE (two child passes of one {args.chunk}-neuron step), '
+                      'summed over the launches of the dominant kernel family; '
+                      'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, per launch')
 
 
 def stage_report(stages, n_steps, n_images_per_step, neurons_per_step, beam,
@@ -829,10 +853,16 @@ def main():
     # committed summary of those passes, not collected live.
     traffic_bytes, traffic_note = None, 'not collected (PMC needs separate rocprofv3 passes)'
     live_reason = None
+    dom_family = max(kernels, key=lambda k: kernels[k]['ms']) if kernels else None
     if live_traffic is not None:
-        traffic_bytes, traffic_note = live_traffic
-        if traffic_bytes is None:
+        families, traffic_note = live_traffic
+        if families is None:
             live_reason, traffic_note = traffic_note, None
+        elif dom_family in families:
+            traffic_bytes = families[dom_family][0]
+            traffic_note += f' ({dom_family}: {families[dom_family][1]} launches in the step)'
+        else:
+            live_reason, traffic_note = f'no PMC rows for the family {dom_family}', None
     for name in ([] if traffic_bytes is not None else
                  ['r5_hbm_traffic.json', 'r4_hbm_traffic.json', 'r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.json']):
         tpath = REPO / 'profiles' / name
@@ -865,8 +895,8 @@ def main():
         pool_bytes = pooled_bytes_per_image(masks[:args.chunk])
         # the DOMINANT kernel priced on its own launches (milan_profile_read_kernels):
         # algorithmic FLOPs of its launches / their summed HIP-event time
-        kname = {'pp32_256': 'igemm_split16_pp32_kernel', 'pp32_128':
-                 'igemm_split16_pp32n_kernel<128>', 'split_other':
+        kname = {'pp32_256': 'igemm_split16_pp32_kernel + its tap-inner form igemm_split16_pp32t_kernel<256> (one tile function)', 'pp32_128':
+                 'igemm_split16_pp32n_kernel<128> + igemm_split16_pp32t_kernel<128>', 'split_other':
                  'igemm_split16_kernel / igemm_kernel<SPLIT> (other split tiles)',
                  'f32': 'igemm_kernel (v_mfma_f32_32x32x2_f32)', 'chain': 'chain_kernel',
                  'chain_wide': 'chain3_kernel (layer3 expand -> reduce)',
