@@ -1721,8 +1721,9 @@ struct PpLoader {
 // LDS: [A0 32K][A1 32K][W0 32K][A2 32K][W1 32K].
 // BNW: columns of the output tile.  256: wave tiles 128 x 64 (2 x 4 waves).  128 (round 4, the
 // N = 128 layers of layer2 and the odd-width products): wave tiles 64 x 64 (4 x 2 waves), the
-// SAME loader -- W rows 128..255 of a slot carry out-of-range offsets, for which the DMA writes
-// zeros without a fetch -- so every counted wait is the 256-column kernel's.
+// SAME loader minus the W pieces of rows 128..255, which no wave tile reads (round 5; they had
+// been issued with out-of-range offsets = zero fill): every counted wait names the A pieces
+// issued behind them, so the waits are the 256-column kernel's.
 // TAPI (GemmArgs::tap_inner): k runs (32-channel slice, tap, channel).  The KH * KW shifted
 // copies of a slice are then requested in consecutive pairs -- the second to ninth find their
 // lines in L2 (tap-major, a line is asked for again 8 pairs = 8 x 32 workgroups x 32 KB later
@@ -1873,8 +1874,10 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
       asm volatile("" : "+s"(woff));
       float* dst = w_slot(SLOT) + woff;
       const int soff = L.iw * (BKP * 4);
+      // (128-column tiles: W rows 128..255 of a slot are never read -- wave tiles end at row 127 --
+      // so their two pieces are not issued; every counted wait names the A pieces behind them)
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
+      for (int it = 0; it < (BNW == 256 ? 4 : 2); ++it)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(L.srd_w, (LDS_AS void*)(dst + it * (64 * BKP)), 16,
                                                  L.vb[it], soff, 0, 0);
     }

@@ -38,13 +38,13 @@ OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 PINNED = {
     'chain3_kernelILb0': {'mfma': 192, 'lds_dma': 64, 'global_load_x4': 104, 'global_store_x4': 72, 'barriers': 14, 'scratch': 4, 'vmcnt': [0, 1, 2, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30]},
     'igemm_split16_pp32_kernel': {'mfma': 576, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
-    'igemm_split16_pp32n_kernelILi128': {'mfma': 288, 'lds_dma': 124, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 53, 'scratch': 0, 'vmcnt': [0, 4]},
+    'igemm_split16_pp32n_kernelILi128': {'mfma': 288, 'lds_dma': 94, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 53, 'scratch': 0, 'vmcnt': [0, 4]},
     'igemm_f16_pp32_kernelILi256ELb0': {'mfma': 384, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
-    'igemm_f16_pp32_kernelILi128ELb0': {'mfma': 192, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
+    'igemm_f16_pp32_kernelILi128ELb0': {'mfma': 192, 'lds_dma': 84, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
     'igemm_split16_pp32t_kernelILi256': {'mfma': 576, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
-    'igemm_split16_pp32t_kernelILi128': {'mfma': 288, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
+    'igemm_split16_pp32t_kernelILi128': {'mfma': 288, 'lds_dma': 84, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
     'igemm_f16_pp32_kernelILi256ELb1': {'mfma': 384, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
-    'igemm_f16_pp32_kernelILi128ELb1': {'mfma': 192, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
+    'igemm_f16_pp32_kernelILi128ELb1': {'mfma': 192, 'lds_dma': 84, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4]},
     'chain_kernelILi128ELi8': {'mfma': 96, 'lds_dma': 14, 'global_load_x4': 40, 'global_store_x4': 24, 'barriers': 6, 'scratch': 6, 'vmcnt': [0, 1, 2, 12]},
     'chain_kernelILi64ELi8ELb0ELi0ELb1': {'mfma': 48, 'lds_dma': 10, 'global_load_x4': 30, 'global_store_x4': 16, 'barriers': 4, 'scratch': 0, 'vmcnt': [0, 2, 12]},
     'chain_kernelILi64ELi8ELb0ELi64ELb1': {'mfma': 72, 'lds_dma': 12, 'global_load_x4': 22, 'global_store_x4': 16, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 2, 4]},
