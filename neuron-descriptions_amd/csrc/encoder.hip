@@ -852,6 +852,65 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
   }
 }
 
+// The same for split-format taps with a lane per 8-CHANNEL GROUP (round 5): a pixel's group is
+// two 16-byte loads (hi, lo) instead of two 2-byte loads per channel, a wave covers 64 groups of
+// one listed pixel -- or 64 / (C / 8) pixels when the level has fewer groups -- and the four
+// waves walk the list interleaved.  grid (n_images, ceil(C / 512)); partial sums are added in a
+// fixed order (slot ascending), so results do not depend on timing (not the bits of
+// masked_pool_kernel<1>: another association of the same fp32 sum).
+__global__ __launch_bounds__(256) void masked_pool_split8_kernel(
+    const float* __restrict__ tap, int P, int C, int level, Levels lv,
+    const int* __restrict__ list_idx, const float* __restrict__ list_w,
+    const int* __restrict__ list_n, float* __restrict__ features, int fstride,
+    int col_off, int img0, float inv_scale, const int* __restrict__ poison,
+    const int* __restrict__ order, int lpp) {
+  __shared__ float part[4 * 64 * 8];
+  const int slot_img = blockIdx.x + img0;
+  const int img = order ? order[slot_img] : slot_img;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = C / 8, pw = 64 / lpp;
+  const int gl = lane % lpp, sub = lane / lpp;
+  const int g = blockIdx.y * 64 + gl;
+  const int slot = wave * pw + sub, nslots = 4 * pw;
+  const long base = (long)img * lv.per_image + lv.off[level];
+  const int cnt = list_n[img * 5 + level];
+  const float* t = tap + (long)blockIdx.x * P * C + (long)g * 8;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+  auto add = [&](int i, float (&acc)[8]) {
+    const float* q = t + (long)list_idx[base + i] * C;
+    const float w = list_w[base + i];
+    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(q);
+    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(q + 4);
+    float v[8];
+    join8_exact(hi, lo, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += w * v[e];
+  };
+  if (g < G) {
+    int i = slot;
+    for (; i + nslots < cnt; i += 2 * nslots) { add(i, a0); add(i + nslots, a1); }
+    if (i < cnt) add(i, a0);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[(wave * 64 + lane) * 8 + e] = a0[e] + a1[e];
+  __syncthreads();
+  if (wave == 0 && sub == 0 && g < G) {
+    float sum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int sb = 0; sb < pw; ++sb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] += part[(w * 64 + sb * lpp + gl) * 8 + e];
+    const bool bad = poison != nullptr && poison[img];
+    float* f = features + (long)img * fstride + col_off + g * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = bad ? __builtin_nanf("") : sum[e] * inv_scale;
+  }
+}
+
 // rows of poisoned images -> NaN (SpatialConvEncoder read-out; see preprocess_kernel)
 __global__ void poison_fill_kernel(float* __restrict__ out, long per_image, int n,
                                    const int* __restrict__ poison) {
@@ -1218,11 +1277,20 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col_off, img0,
                          1.f / c->act_scale, poison, order);
-    else if (split && level > 0)
-      hipLaunchKernelGGL(masked_pool_kernel<1>, dim3(cnt, (C + 63) / 64),
-                         dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off, img0,
-                         1.f / c->act_scale, poison, order);
+    else if (split && level > 0) {
+      // MILAN_POOL_VEC=0: a lane per channel (rounds 1-4; A/B timing)
+      static const bool vec = !(getenv("MILAN_POOL_VEC") && atoi(getenv("MILAN_POOL_VEC")) == 0);
+      const int G = C / 8;
+      if (vec && C % 8 == 0 && (G % 64 == 0 || (G < 64 && 64 % G == 0)) && (col_off % 4) == 0)
+        hipLaunchKernelGGL(masked_pool_split8_kernel, dim3(cnt, (G + 63) / 64), dim3(256), 0, s, tap,
+                           P, C, level, pl.lv, pl.list_idx, pl.list_w, pl.list_n, features, F,
+                           col_off, img0, 1.f / c->act_scale, poison, order, G < 64 ? G : 64);
+      else
+        hipLaunchKernelGGL(masked_pool_kernel<1>, dim3(cnt, (C + 63) / 64),
+                           dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
+                           pl.list_w, pl.list_n, features, F, col_off, img0,
+                           1.f / c->act_scale, poison, order);
+    }
     else
       hipLaunchKernelGGL(masked_pool_kernel<0>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
