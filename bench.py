@@ -345,7 +345,7 @@ def measure_traffic_live(args):
                    '--warmup', '0', '--chunk', str(args.chunk), '--precision',
                    args.precision, '--also-f32-steps', '0', '--cpu-sample', '0',
                    '--no-profile', '--from-host-steps', '0', '--other-configs', '0',
-                   '--live-traffic', '0']
+                   '--fast-steps', '0', '--live-traffic', '0']
             env = dict(os.environ, TMPDIR='/tmp')
             try:
                 r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True,
