@@ -257,8 +257,11 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1,
  *                     tile (csrc/conv3.hip) instead of the implicit GEMM.
  *   MILAN_FUSE_SKIP_EMPTY  exemplars whose mask is all zero pool exact zeros at every
  *                     pyramid level whatever the trunk computes (src/milan/encoders.py:
- *                     310-317): they are left out of the trunk pass (uint8 images; one
- *                     4-byte read-back per encoder pass).
+ *                     310-317): they are left out of the trunk pass (uint8 images).  The
+ *                     number of images with work stays ON THE DEVICE (round 6): every
+ *                     trunk launch is sized for the whole batch and reads the count
+ *                     itself, workgroups beyond it exit -- nothing is read back and
+ *                     the stream is never synchronised (rounds 5's form did both).
  * Default: all five (environment MILAN_CHAIN=<flags> overrides at context creation). */
 enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
        MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): the role ping-pong of csrc/chain3.hip

@@ -152,10 +152,12 @@ int milan_create(milan_ctx** out, int device, const milan_dims* dims) {
 void milan_destroy(milan_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // (the thread-local status word must not outlive the context it points into: a later
+  // ctx-less call -- milan_conv2d_nhwc -- would atomicOr into freed device memory)
+  if (status_word() == c->status) set_status_word(nullptr);
   for (auto& g : c->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (void* p : c->owned) (void)hipFree(p);
-  if (c->host_count) (void)hipHostFree(c->host_count);
   delete c;
 }
 
@@ -413,6 +415,7 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
                       const float* residual, float* y, int precision,
                       milan_stream stream) {
   MILAN_REQUIRE(x && weight_oihw && y, MILAN_ERR_ARG, "conv2d: null argument");
+  set_status_word(nullptr);  // ctx-less entry point: nobody listens for saturation here
   // precision 3 (test hook only): split-f16 with the LDS-strip 3x3 kernel forced;
   // precision 4 (test hook only): split-f16 with k in tap-major order (GemmArgs::Wt unset)
   const bool force_strip = precision == 3, tap_major = precision == 4;

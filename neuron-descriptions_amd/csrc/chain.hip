@@ -129,6 +129,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   float* rstrip = strip;  // 32 rows x 64 floats, unpadded, at the start of the strip
   float* biasl = smem + STAGES * kTileFloats + NW * (32 * kSRow);
 
+  // (row count on the device: workgroups whose pixels lie beyond it exit, the one that
+  // straddles it runs its ragged-tail path -- GemmArgs::m_live)
+  g.M = live_rows(g.m_live, g.m_live_mul, g.M);
+  if ((long)blockIdx.x * (NW * 32) >= g.M) return;
   const long m0 = (long)blockIdx.x * (NW * 32) + wave * 32;   // wave's first pixel
   const long mfrag = (m0 + px < g.M) ? m0 + px : (long)g.M - 1;
   const bool tail = (long)(blockIdx.x + 1) * (NW * 32) > g.M;  // workgroup-uniform

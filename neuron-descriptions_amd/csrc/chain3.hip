@@ -113,6 +113,12 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
     }
   };
   if constexpr (PROF) tlast = __builtin_readcyclecounter();
+  // (row count on the device, GemmArgs::m_live: the persistent walk covers the live tiles)
+  if (g.m_live != nullptr) {
+    g.M = live_rows(g.m_live, g.m_live_mul, g.M);
+    ntiles = (g.M + 127) / 128;
+    if ((int)blockIdx.x >= ntiles) return;
+  }
   constexpr int P = 256, N3 = 1024, N1 = 256, NSLAB = 16;
   constexpr int NPAIR = 4 * (NSLAB + 1);  // weight-tile pairs = half-slots
   extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -127,6 +127,13 @@ struct GemmArgs {
   const long long* lse_tgt;  // EPI_LSE: target column of row m at lse_tgt[m * lse_tgt_stride]
   long lse_tgt_stride;
   float* lse_x;              // EPI_LSE: [M] the target column's x
+  // Row count known only on the DEVICE (round 6; encoder.hip, MILAN_FUSE_SKIP_EMPTY): when
+  // m_live != nullptr the launch is sized for M rows but only the first min(M, *m_live *
+  // m_live_mul) hold work -- the kernel reads the word with a scalar load, workgroups whose
+  // tiles lie beyond it exit, the tile that straddles it masks its rows as for a ragged M.
+  // No host read-back, no hipStreamSynchronize (live_rows() below).
+  const int* m_live;
+  int m_live_mul;
 };
 
 enum OutMode : int { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_SPLIT8 = 2, OUT_F16 = 3 };
@@ -172,6 +179,8 @@ struct ChainArgs {
   long long* prof;       // timing experiments: per-workgroup phase cycles (8 per WG)
   int NR;                // output channels of the reduce conv (0 = P; 2 P at a stage boundary)
   unsigned* status;      // filled by the launcher (status_word())
+  const int* m_live;     // device-side row count, see GemmArgs::m_live (nullptr: M rows)
+  int m_live_mul;
 };
 bool chain_supported(int P, int KD, int NR = 0);
 int launch_chain(const ChainArgs& a, hipStream_t s);
@@ -201,6 +210,7 @@ struct StemArgs {
   const unsigned* lut;
   const int* order;      // batch slot -> image number (encoder.hip, MILAN_FUSE_SKIP_EMPTY) or nullptr
   int W;
+  const int* n_live;     // device-side image count (<= n) or nullptr, see GemmArgs::m_live
 };
 bool stem_fused_supported(int cout, int Kp);
 int launch_stem_fused(const StemArgs& a, hipStream_t s);
@@ -217,6 +227,7 @@ struct Conv3Args {
   int debug;             // timing experiments: 1 no MFMA, 2 no epilogue, 4 no DMA, 8 no hand-over
   long long* prof;       // experiments build: per-phase cycle sums of workgroup 0 (16 values)
   unsigned* status;      // filled by the launcher (status_word())
+  const int* n_live;     // device-side image count (<= n) or nullptr, see GemmArgs::m_live
 };
 bool conv3_p64_supported(int cin, int cout, int kh, int kw, int stride, int pad);
 int launch_conv3_p64(const Conv3Args& a, hipStream_t s);
@@ -327,6 +338,17 @@ struct Arena {
     return reinterpret_cast<T*>(base + o);
   }
 };
+
+// ---- device-side row / image counts (GemmArgs::m_live) --------------------------------
+// min(bound, *live * mul) through a SCALAR load (constant address space: the word was
+// written by an earlier kernel of the same stream and does not change while this one runs;
+// the scalar cache is invalidated at every dispatch, as for the kernel arguments).
+__device__ __forceinline__ int live_rows(const int* live, int mul, int bound) {
+  if (live == nullptr) return bound;
+  typedef const int __attribute__((address_space(4)))* KWord;
+  const long v = (long)*(KWord)(uintptr_t)live * mul;
+  return v < bound ? (int)v : bound;
+}
 
 // ---- split-f16 storage format, device side (one implementation for every kernel) -----
 // 8 fp32 -> (hi, lo) f16x8 pair; hi saturates instead of overflowing to inf:
@@ -462,7 +484,6 @@ struct milan_ctx {
   int act_scale_log2 = 5;
   float *bn1_scale_s = nullptr, *bn1_shift_s = nullptr;
   unsigned* stem_lut = nullptr;  // byte -> split value table of the uint8 stem (StemArgs::lut), lazily
-  int* host_count = nullptr;     // pinned host word for the encoder's 4-byte read-back (MILAN_FUSE_SKIP_EMPTY), lazily
   // device status word (MILAN_STATUS_* bits, milan_status): ORed by the split epilogues when
   // a value hit the +-65504 clamp and by the input conversion when a pixel was not finite
   unsigned* status = nullptr;

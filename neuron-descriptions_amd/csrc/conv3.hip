@@ -141,6 +141,7 @@ __global__ __launch_bounds__(512, 1) void conv3_p64_kernel(Conv3Args a) {
   }
 
   // ---- tile sequence (XCD x walks images x, x + 8, ...; see stem.hip) ----
+  a.n = live_rows(a.n_live, 1, a.n);   // (image count on the device, GemmArgs::m_live)
   const int tiles = a.tiles_y * a.tiles_x;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   auto decode = [&](int i, int* img, int* ty, int* tx) -> bool {

@@ -196,7 +196,9 @@ static int pack_conv(milan_ctx* c, const std::string& conv,
       const int taps = out->kh * out->kw;
       MILAN_TRY(dev_alloc(c, (void**)&out->wst, sizeof(float) * (size_t)out->cout * out->Kp));
       MILAN_TRY(make_slice_major(out->ws, out->cout, taps, out->cin, 4, 2, out->wst, s));
-      if (out->wf) {
+      // (slice_major_kernel assumes whole slices: cin % 32 for split rows -- guaranteed by
+      // the enclosing test -- and cin % 64 for the plain f16 rows)
+      if (out->wf && out->cin % 64 == 0) {
         MILAN_TRY(dev_alloc(c, (void**)&out->wft, sizeof(float) * (size_t)out->cout * out->Kp / 2));
         MILAN_TRY(make_slice_major(out->wf, out->cout, taps, out->cin, 8, 1, out->wft, s));
       }
@@ -409,11 +411,13 @@ __global__ void preprocess_kernel(const T* __restrict__ img, long n_pix_total,
                                   const void* __restrict__ mul = nullptr,
                                   int mul_u8 = 1, int* __restrict__ poison = nullptr,
                                   unsigned* __restrict__ status = nullptr,
-                                  const int* __restrict__ order = nullptr) {
+                                  const int* __restrict__ order = nullptr,
+                                  const int* __restrict__ live = nullptr) {
   // the byte->float product is rounded on its own, as in the reference: no
   // contraction into the mean subtraction
 #pragma clang fp contract(off)
   const float inv255 = (float)(1.0 / 255.0);
+  if (live) n_pix_total = min(n_pix_total, (long)*live * hw);   // (image count on the device)
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < n_pix_total;
        p += (long)gridDim.x * blockDim.x) {
     const long n = p / hw, r = p - n * hw;
@@ -450,7 +454,9 @@ __global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, int n,
                                        int H, int W, int C4, int Ho, int Wo,
                                        const float4* __restrict__ scale,
                                        const float4* __restrict__ shift,
-                                       float4* __restrict__ y) {
+                                       float4* __restrict__ y,
+                                       const int* __restrict__ live = nullptr) {
+  if (live) n = min(n, *live);   // (image count on the device)
   const long total = (long)n * Ho * Wo * C4;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
@@ -509,7 +515,10 @@ __global__ void split_to_f32_kernel(const float* __restrict__ x, long groups,
 // split-format groups -> plain f16 (fast mode, at the layer2 -> layer3 boundary):
 // f16(hi + lo), one rounding of the 22-bit value
 __global__ void split_to_f16_kernel(const float* __restrict__ x, long groups,
-                                    float* __restrict__ y) {
+                                    float* __restrict__ y,
+                                    const int* __restrict__ live = nullptr,
+                                    long groups_per_image = 0) {
+  if (live) groups = min(groups, (long)*live * groups_per_image);   // (image count on the device)
   for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < groups;
        q += (long)gridDim.x * blockDim.x) {
     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(x + q * 8);
@@ -534,11 +543,13 @@ __global__ void preprocess_pairs_kernel(const T* __restrict__ img, long n_groups
                                         const void* __restrict__ mul = nullptr,
                                         int mul_u8 = 1, int* __restrict__ poison = nullptr,
                                         unsigned* __restrict__ status = nullptr,
-                                        const int* __restrict__ order = nullptr) {
+                                        const int* __restrict__ order = nullptr,
+                                        const int* __restrict__ live = nullptr) {
 #pragma clang fp contract(off)  // see preprocess_kernel
   const float inv255 = (float)(1.0 / 255.0);
   const long hw = (long)H * W;
   float sat = 0.f;
+  if (live) n_groups = min(n_groups, (long)*live * H * G);   // (image count on the device)
   for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n_groups;
        q += (long)gridDim.x * blockDim.x) {
     const int p = q % G;
@@ -613,8 +624,10 @@ __global__ void bn_relu_maxpool_split_kernel(const float* __restrict__ x, int n,
                                              const float* __restrict__ scale,
                                              const float* __restrict__ shift,
                                              float* __restrict__ y,
-                                             unsigned* __restrict__ status) {
+                                             unsigned* __restrict__ status,
+                                             const int* __restrict__ live = nullptr) {
   const int C8 = C >> 3;
+  if (live) n = min(n, *live);   // (image count on the device)
   const long total = (long)n * Ho * Wo * C8;
   float sat = 0.f;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
@@ -806,8 +819,11 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
     const int* __restrict__ list_n, float* __restrict__ features, int fstride,
     int col_off, int img0, float inv_scale, const int* __restrict__ poison = nullptr,
-    const int* __restrict__ order = nullptr) {
+    const int* __restrict__ order = nullptr, const int* __restrict__ live = nullptr) {
   __shared__ float part[4][64];
+  // (image count on the device: slots beyond it hold no image -- their feature rows were
+  // zero-filled -- and order[] is only defined below it)
+  if (live != nullptr && (int)blockIdx.x + img0 >= *live) return;
   // `tap` points at slot img0 of the batch; lists / features are indexed by the image
   // number (`order`: the batch holds only the images with a non-empty mask, in this order)
   const int img = order ? order[blockIdx.x + img0] : blockIdx.x + img0;
@@ -863,9 +879,10 @@ __global__ __launch_bounds__(256) void masked_pool_split8_kernel(
     const int* __restrict__ list_idx, const float* __restrict__ list_w,
     const int* __restrict__ list_n, float* __restrict__ features, int fstride,
     int col_off, int img0, float inv_scale, const int* __restrict__ poison,
-    const int* __restrict__ order, int lpp) {
+    const int* __restrict__ order, int lpp, const int* __restrict__ live = nullptr) {
   __shared__ float part[4 * 64 * 8];
   const int slot_img = blockIdx.x + img0;
+  if (live != nullptr && slot_img >= *live) return;   // (see masked_pool_kernel)
   const int img = order ? order[slot_img] : slot_img;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int G = C / 8, pw = 64 / lpp;
@@ -1177,29 +1194,32 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
 
   // 1b. images with an all-zero mask pool exact zeros at every level: they stay out of the
   // trunk pass (MILAN_FUSE_SKIP_EMPTY; uint8 images only -- a float image may hold a NaN
-  // pixel, whose image the reference turns into NaN even under a zero mask).  The batch
-  // below is the `n` images with work, slot j = image order[j]; one 4-byte read-back.
+  // pixel, whose image the reference turns into NaN even under a zero mask).  Batch slot j
+  // holds image order[j]; HOW MANY slots hold work stays on the device (round 6: `live`, one
+  // word written by compact_images_kernel): every launch below is sized for all n images
+  // and reads the count itself (GemmArgs::m_live), so nothing is read back and the stream
+  // is never synchronised -- the header's "all work is enqueued on `stream`" holds again
+  // and the whole pass can be captured into a hipGraph.
   const int n_all = n;
   const int* order = nullptr;
+  const int* live = nullptr;
   if (!spatial && masks != nullptr && image_dtype == MILAN_DTYPE_U8 && c->calib == nullptr &&
       (c->fusion & MILAN_FUSE_SKIP_EMPTY)) {
     hipLaunchKernelGGL(compact_images_kernel, dim3(1), dim3(1024), 0, s, pl.list_n, n_all,
                        pl.bbox, pl.order, pl.bbox_c, pl.count);
     MILAN_CHECK_HIP(hipGetLastError());
-    if (c->host_count == nullptr)
-      MILAN_CHECK_HIP(hipHostMalloc((void**)&c->host_count, sizeof(int), hipHostMallocDefault));
-    MILAN_CHECK_HIP(hipMemcpyAsync(c->host_count, pl.count, sizeof(int), hipMemcpyDeviceToHost, s));
-    MILAN_CHECK_HIP(hipStreamSynchronize(s));
-    const int live = *c->host_count;
-    MILAN_REQUIRE(live >= 0 && live <= n_all, MILAN_ERR_STATE, "encode: image compaction failed");
-    if (live < n_all) {
-      MILAN_CHECK_HIP(hipMemsetAsync(features, 0, sizeof(float) * (size_t)n_all * c->d.feature_size, s));
-      if (live == 0) return 0;
-      n = live;
-      order = pl.order;
-    }
+    // rows of the images without work: exact zeros (the pooling writes the others)
+    MILAN_CHECK_HIP(hipMemsetAsync(features, 0, sizeof(float) * (size_t)n_all * c->d.feature_size, s));
+    order = pl.order;
+    live = pl.count;
   }
   const int* const bbox = order ? pl.bbox_c : pl.bbox;
+  // every trunk launch carries the device-side image count (rows per image = Ho x Wo)
+  auto launch_live = [&](GemmArgs g) -> int {
+    g.m_live = live;
+    g.m_live_mul = g.Ho * g.Wo;
+    return launch_gemm(g, s);
+  };
 
   // split-f16 mode needs every bottleneck conv to have a split weight copy
   bool split = c->precision == MILAN_PRECISION_SPLIT_F16 && wd % 8 == 0;
@@ -1247,7 +1267,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       hipLaunchKernelGGL(preprocess_pairs_kernel<uint8_t>, dim3(blocks),
                          dim3(256), 0, s, (const uint8_t*)images, np, H, W, G,
                          m0, m1, m2, s0, s1, s2, pl.in4, mul, mul_u8, nullptr, c->status,
-                         order);
+                         order, live);
     else if (pair_stem)
       hipLaunchKernelGGL(preprocess_pairs_kernel<float>, dim3(blocks), dim3(256),
                          0, s, (const float*)images, np, H, W, G, m0, m1, m2, s0,
@@ -1255,7 +1275,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     else if (image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(blocks), dim3(256), 0,
                          s, (const uint8_t*)images, np, H * W, m0, m1, m2, s0, s1,
-                         s2, (float4*)pl.in4, mul, mul_u8, nullptr, nullptr, order);
+                         s2, (float4*)pl.in4, mul, mul_u8, nullptr, nullptr, order, live);
     else
       hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s,
                          (const float*)images, np, H * W, m0, m1, m2, s0, s1, s2,
@@ -1276,7 +1296,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       hipLaunchKernelGGL(masked_pool_kernel<2>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                          pl.list_w, pl.list_n, features, F, col_off, img0,
-                         1.f / c->act_scale, poison, order);
+                         1.f / c->act_scale, poison, order, live);
     else if (split && level > 0) {
       // MILAN_POOL_VEC=0: a lane per channel (rounds 1-4; A/B timing)
       static const bool vec = !(getenv("MILAN_POOL_VEC") && atoi(getenv("MILAN_POOL_VEC")) == 0);
@@ -1284,17 +1304,17 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       if (vec && C % 8 == 0 && (G % 64 == 0 || (G < 64 && 64 % G == 0)) && (col_off % 4) == 0)
         hipLaunchKernelGGL(masked_pool_split8_kernel, dim3(cnt, (G + 63) / 64), dim3(256), 0, s, tap,
                            P, C, level, pl.lv, pl.list_idx, pl.list_w, pl.list_n, features, F,
-                           col_off, img0, 1.f / c->act_scale, poison, order, G < 64 ? G : 64);
+                           col_off, img0, 1.f / c->act_scale, poison, order, G < 64 ? G : 64, live);
       else
         hipLaunchKernelGGL(masked_pool_kernel<1>, dim3(cnt, (C + 63) / 64),
                            dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
                            pl.list_w, pl.list_n, features, F, col_off, img0,
-                           1.f / c->act_scale, poison, order);
+                           1.f / c->act_scale, poison, order, live);
     }
     else
       hipLaunchKernelGGL(masked_pool_kernel<0>, dim3(cnt, (C + 63) / 64),
                          dim3(256), 0, s, tap, P, C, level, pl.lv, pl.list_idx,
-                         pl.list_w, pl.list_n, features, F, col_off, img0, 1.f, poison, order);
+                         pl.list_w, pl.list_n, features, F, col_off, img0, 1.f, poison, order, live);
     MILAN_CHECK_HIP(hipGetLastError());
     return 0;
   };
@@ -1325,6 +1345,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         sa.in = nullptr; sa.in_u8 = (const unsigned char*)images; sa.lut = c->stem_lut;
         sa.order = order; sa.W = W;
       }
+      sa.n_live = live;
       sa.acc_scale = c->stem_pair.ws_inv;
       sa.scale = c->bn1_scale_s; sa.shift = c->bn1_shift_s;  // (activation scale)
       sa.raw = spatial ? nullptr : pl.raw; sa.y = pl.x0;
@@ -1340,7 +1361,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     } else {
     {
       StageScope scope(MILAN_STAGE_ENC_STEM, s);
-      MILAN_TRY(launch_gemm(g, s));
+      MILAN_TRY(launch_live(g));
     }
     MILAN_TRY(pool(pl.raw, 0, wd, 0));
     stage.emplace(MILAN_STAGE_ENC_STEM_TAIL, s);
@@ -1349,12 +1370,12 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (split)
       hipLaunchKernelGGL(bn_relu_maxpool_split_kernel, dim3(blocks), dim3(256), 0,
                          s, pl.raw, n, pl.h1, pl.w1, wd, pl.hp, pl.wp,
-                         c->bn1_scale_s, c->bn1_shift_s, pl.x0, c->status);
+                         c->bn1_scale_s, c->bn1_shift_s, pl.x0, c->status, live);
     else
       hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, s,
                          (const float4*)pl.raw, n, pl.h1, pl.w1, wd / 4, pl.hp,
                          pl.wp, (const float4*)c->bn1_scale,
-                         (const float4*)c->bn1_shift, (float4*)pl.x0);
+                         (const float4*)c->bn1_shift, (float4*)pl.x0, live);
     MILAN_CHECK_HIP(hipGetLastError());
     stage.reset();
     }
@@ -1365,7 +1386,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
 
   // (calibration: every conv output of the fp32 pass is folded into the running maximum)
   auto gemm_t = [&](const GemmArgs& g) -> int {
-    MILAN_TRY(launch_gemm(g, s));
+    MILAN_TRY(launch_live(g));
     if (c->calib && !split) MILAN_TRY(track(g.C, (long)g.M * g.N));
     return 0;
   };
@@ -1383,7 +1404,8 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       // the residual stream leaves the split format: f16(hi + lo) into the spare buffer
       const long groups = (long)n * h * w * ((wd * 4) << 1) / 8;   // layer2's output channels
       const int nb = (int)((groups + 255) / 256 < 16384 ? (groups + 255) / 256 : 16384);
-      hipLaunchKernelGGL(split_to_f16_kernel, dim3(nb), dim3(256), 0, s, x, groups, pl.ds);
+      hipLaunchKernelGGL(split_to_f16_kernel, dim3(nb), dim3(256), 0, s, x, groups, pl.ds, live,
+                         groups / n);
       MILAN_CHECK_HIP(hipGetLastError());
       y = x; x = pl.ds;
     }
@@ -1392,9 +1414,9 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       int h1, w1, h2, w2, h3, w3;
       if (fast && li >= 2) {
         GemmArgs g1 = conv_args_f16(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr, c->zero, &h1, &w1);
-        MILAN_TRY(launch_gemm(g1, s));
+        MILAN_TRY(launch_live(g1));
         GemmArgs g2 = conv_args_f16(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU, nullptr, c->zero, &h2, &w2);
-        MILAN_TRY(launch_gemm(g2, s));
+        MILAN_TRY(launch_live(g2));
         if (b.has_down) {
           // c3 and the downsample as ONE GEMM over [t2 | x(strided)]
           GemmArgs g3 = conv_args_f16(b.c3d, pl.t2, n, h2, w2, y, EPI_BIAS_RELU, nullptr, c->zero, &h3, &w3);
@@ -1406,10 +1428,10 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
           g3.a2_pix_stride = b.down.cin / 2;
           g3.a2_img_stride = (long)h * w * (b.down.cin / 2);
           g3.flop_k = b.c3.K + b.down.K;
-          MILAN_TRY(launch_gemm(g3, s));
+          MILAN_TRY(launch_live(g3));
         } else {
           GemmArgs g3 = conv_args_f16(b.c3, pl.t2, n, h2, w2, y, EPI_BIAS_RES_RELU, x, c->zero, &h3, &w3);
-          MILAN_TRY(launch_gemm(g3, s));
+          MILAN_TRY(launch_live(g3));
         }
         float* tmp = x; x = y; y = tmp;
         h = h3; w = w3;
@@ -1461,6 +1483,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         Conv3Args ca{};
         ca.in = pl.t1; ca.ws = b.c2.ws; ca.bias = b.c2.bias_s; ca.acc_scale = b.c2.ws_inv;
         ca.out = pl.t2; ca.zero = c->zero; ca.n = n; ca.h = h1; ca.w = w1;
+        ca.n_live = live;
         MILAN_TRY(launch_conv3_p64(ca, s));
       } else {
         MILAN_TRY(gemm_t(g2));
@@ -1494,6 +1517,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
           ca.T2 = pl.t2; ca.X = y; ca.W1 = nb.c1.ws; ca.bias1 = nb.c1.bias_s;
           ca.T1 = pl.t1; ca.M = n * h2 * w2; ca.P = P; ca.scale1 = nb.c1.ws_inv;
           ca.NR = NR;
+          ca.m_live = live; ca.m_live_mul = h2 * w2;
           if (plain) {
             ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias_s; ca.R = x; ca.scale3 = b.c3.ws_inv;
           } else {

@@ -573,6 +573,14 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs& g,
   }
 }
 
+// tiles_m of a launch whose row count lives on the device: the launcher's value is an upper
+// bound; workgroups beyond tiles_m(live) x tiles_n exit, xcd_tile() maps over the live count
+__device__ __forceinline__ int live_tiles_m(GemmArgs& g, int tiles_m, int BM) {
+  if (g.m_live == nullptr) return tiles_m;
+  g.M = live_rows(g.m_live, g.m_live_mul, g.M);
+  return (g.M + BM - 1) / BM;
+}
+
 template <int BM, int BN, int STAGES, bool CIN32, bool SPLIT>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_kernel(
     GemmArgs g, int tiles_m, int tiles_n) {
@@ -596,6 +604,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_kernel(
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   // XCD-aware bijective remap (block b runs on XCD b % 8).
+  tiles_m = live_tiles_m(g, tiles_m, BM);
+  if ((int)blockIdx.x >= tiles_m * tiles_n) return;
   int tile;
   {
     const int T = tiles_m * tiles_n;
@@ -1140,6 +1150,7 @@ __global__ __launch_bounds__((BM / 128) * (BN / 64) * 64, 2) void igemm_split16_
     GemmArgs g, int tiles_m, int tiles_n) {
   // one tile per workgroup (gridDim.x == tiles), or persistent workgroups walking
   // tiles q = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8: q stays on its XCD)
+  tiles_m = live_tiles_m(g, tiles_m, BM);
   const int T = tiles_m * tiles_n;
   for (int q = blockIdx.x; q < T; q += gridDim.x) {
     const int tile = xcd_tile(q, T);
@@ -1178,6 +1189,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_linp_kernel(GemmArgs g,
   float* As = smem;                        // [STAGES][BM*16]
   float* Bs = smem + STAGES * BM * BK;     // [STAGES][BN*16]; the epilogue's staging
   const int HoWo = g.Ho * g.Wo;
+  tiles_m = live_tiles_m(g, tiles_m, BM);
   const int T = tiles_m * tiles_n;
   const int nk = g.Kp / BK;  // >= AHEAD (launcher)
 
@@ -1444,8 +1456,10 @@ __device__ __forceinline__ GemmArgs reload_gemm_args() {
 #pragma unroll
   for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) words[i] = kw[i];
   __builtin_memcpy(&g, words, sizeof(GemmArgs));
+  g.M = live_rows(g.m_live, g.m_live_mul, g.M);   // (GemmArgs::m_live: row count on the device)
   return g;
 }
+
 
 __device__ __forceinline__ void split16_pp_tile(int tile_m, int tile_n, int tid) {
   const GemmArgs g = reload_gemm_args();
@@ -2088,6 +2102,7 @@ __device__ __forceinline__ void split16_pp32_tile(int tile_m, int tile_n, int ti
 template <int BNW>
 __global__ __launch_bounds__(512, 2) void igemm_split16_pp32n_kernel(GemmArgs g, int tiles_m,
                                                                      int tiles_n) {
+  tiles_m = live_tiles_m(g, tiles_m, 256);
   const int T = tiles_m * tiles_n;
   int q = blockIdx.x;
   if (q >= T) return;
@@ -2118,6 +2133,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp32n_kernel(GemmArgs g,
 __global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, int tiles_m,
                                                                     int tiles_n) {
   // (the 256-column form keeps its round-4 name: profiles and tools key on it)
+  tiles_m = live_tiles_m(g, tiles_m, 256);
   const int T = tiles_m * tiles_n;
   const int q = blockIdx.x;
   if (q >= T) return;
@@ -2132,6 +2148,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp32_kernel(GemmArgs g, 
 template <int BNW>
 __global__ __launch_bounds__(512, 2) void igemm_split16_pp32t_kernel(GemmArgs g, int tiles_m,
                                                                      int tiles_n) {
+  tiles_m = live_tiles_m(g, tiles_m, 256);
   const int T = tiles_m * tiles_n;
   const int q = blockIdx.x;
   if (q >= T) return;
@@ -2145,6 +2162,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp32t_kernel(GemmArgs g,
 // fast mode (GemmArgs::f16): the same tile with one MFMA per 16 real k
 template <int BNW, bool TAPI>
 __global__ __launch_bounds__(512, 2) void igemm_f16_pp32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  tiles_m = live_tiles_m(g, tiles_m, 256);
   const int T = tiles_m * tiles_n;
   const int q = blockIdx.x;
   if (q >= T) return;
@@ -2159,6 +2177,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp_kernel(GemmArgs g, in
                                                                   int tiles_n) {
   // one tile per workgroup (gridDim.x == tiles), or workgroups walking tiles q = blockIdx.x,
   // + gridDim.x, ... (gridDim.x a multiple of 8: q stays on its XCD)
+  tiles_m = live_tiles_m(g, tiles_m, 256);
   const int T = tiles_m * tiles_n;
   for (int q = blockIdx.x; q < T; q += gridDim.x) {
     const int tile = xcd_tile(q, T);
@@ -2176,6 +2195,8 @@ __global__ __launch_bounds__(512, 2) void igemm_split16_pp_kernel(GemmArgs g, in
 template <int BM, int BN, int STAGES>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 2) void igemm_split16_tm2_kernel(
     GemmArgs g, int tiles_m, int tiles_n) {
+  tiles_m = live_tiles_m(g, tiles_m, BM);
+  if ((int)blockIdx.x >= tiles_m * tiles_n) return;
   const int tile = xcd_tile(blockIdx.x, tiles_m * tiles_n);
   const int tile_m = tile / tiles_n;
   split16_tile<BM, BN, STAGES, 0, 2>(g, tile_m, tile - tile_m * tiles_n);
@@ -2696,7 +2717,9 @@ static int launch_split16_tm2(const GemmArgs& g, hipStream_t s) {
 static bool tap_inner_wanted(const GemmArgs& g) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("MILAN_TAP_INNER"); on = e ? atoi(e) : 1; }
-  return on && g.Wt && !g.A2 && g.KH * g.KW > 1 && g.KH * g.KW <= 32 && g.K == g.Kp;
+  // (Cin in 4-byte units: whole 32-slot slices, which is what slice_major_kernel packed)
+  return on && g.Wt && !g.A2 && g.KH * g.KW > 1 && g.KH * g.KW <= 32 && g.K == g.Kp &&
+         g.Cin % 32 == 0;
 }
 
 template <int BNW>

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void stem_fused_kernel(St
     ld_col[k] = gi - ld_row[k] * kInC;
     ld_off[k] = plane * 4;
   }
+  a.n = live_rows(a.n_live, 1, a.n);   // (image count on the device, GemmArgs::m_live)
   const int tiles = a.tiles_y * a.tiles_x;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   // tile sequence of this workgroup: XCD x walks images x, x + 8, ... tile by tile,

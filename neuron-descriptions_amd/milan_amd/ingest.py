@@ -105,10 +105,11 @@ class ChunkPrefetcher:
             ahead = None
             # One-chunk lookahead on the COPY queue too: if chunk k+1 is already staged, its H2D
             # is requested before chunk k is handed out.  A consumer that synchronises inside
-            # its call (the encoder's 4-byte read-back, MILAN_FUSE_SKIP_EMPTY) and then queues a
-            # result D2H would otherwise submit that D2H -- blocked until chunk k is computed --
-            # ahead of the next H2D, which then ran AFTER chunk k instead of under it (measured:
-            # 34 ms per 640-neuron chunk, tools/debug_host_loop.py).  Never waits for a slow fetch.
+            # its call (round 5's encoder did: a 4-byte read-back; round 6's does not, but a
+            # guarded call still reads the status word) and then queues a result D2H would
+            # otherwise submit that D2H -- blocked until chunk k is computed -- ahead of the
+            # next H2D, which then ran AFTER chunk k instead of under it (measured: 34 ms per
+            # 640-neuron chunk, tools/debug_host_loop.py).  Never waits for a slow fetch.
             if k + 1 < self.n:
                 try:
                     ahead = enqueue(self._q.get(timeout=0.002))

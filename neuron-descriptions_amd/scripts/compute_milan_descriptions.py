@@ -4,7 +4,10 @@ Command-line contract of the reference's `scripts/compute_milan_descriptions.py`
 (positional `model dataset`, `--temperature --beam-size --data-dir
 --results-dir --milan --device`, CSV `layer,unit,description` named
 `<model>_<dataset>.csv`), so existing job scripts keep working.  Additions:
-`--milan-path` (there is no downloader here) and multi-GPU sharding -- with
+`--milan-path` (there is no downloader here), `--precision {auto,split_f16,f32}`
+(default `auto`: the split-f16 MFMA path the published throughput belongs to, a
+call whose activations leave its range is rerun in exact fp32 with a warning;
+`f32` = the reference's arithmetic at a third of the speed) and multi-GPU sharding -- with
 `--gpus N` (the script starts its own N ranks) or under `torchrun
 --nproc-per-node N` every rank describes a contiguous block of the neurons and
 rank 0 writes the CSV in the reference's order.
@@ -42,6 +45,10 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument('--results-dir', type=pathlib.Path,
                    help='root dir for final results')
     p.add_argument('--device', help='manually set device (default: cuda)')
+    p.add_argument('--precision', choices=('auto', 'split_f16', 'f32'), default=None,
+                   help='arithmetic of the HIP path: auto = split_f16 with a loud '
+                   'per-call fallback to f32 (default, or $MILAN_PRECISION), '
+                   'split_f16 = raise on saturation, f32 = exact fp32 MFMA')
     p.add_argument('--gpus', type=int, default=1,
                    help='GPUs of this node to shard the neurons over: N > 1 '
                    'without torchrun starts N ranks itself (default: 1)')
@@ -95,6 +102,8 @@ def main(argv=None) -> None:
     # rank 0 reads the checkpoint; the others get it by RCCL broadcast
     decoder = milan.pretrained_sharded(args.milan, path=args.milan_path,
                                        device=device)
+    if args.precision is not None:
+        decoder.precision = args.precision
     dataset = milannotations.load(
         key, path=env_dir(args.data_dir, 'MILAN_DATA_DIR', 'data') / key)
     captions = describe_shard(decoder, dataset, world, rank,

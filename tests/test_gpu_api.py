@@ -169,12 +169,18 @@ def test_save_load_roundtrip_gives_same_descriptions(model, tmp_path):
 
 
 def test_precision_switch_gives_same_captions(model):
-    """decoder.precision = 'split_f16' is an opt-in speed mode with fp32-class
-    error: same captions, features within the encoder tolerance."""
+    """decoder.precision: 'auto' (the default since round 6: split_f16 with the loud
+    per-call fallback to f32) / 'split_f16' / 'f32' -- fp32-class error in all of them:
+    same captions, features within the encoder tolerance."""
     dec, sd = model
     images, masks = synthetic.exemplars(4, k=K, size=SIZE, seed=25)
-    assert dec.precision == 'f32'
+    import os
+    assert dec.precision == os.environ.get('MILAN_PRECISION', 'auto')
+    auto = dec(images, masks)
+    assert dec._context().precision == ('f32' if dec.precision == 'f32' else 'split_f16')
+    dec.precision = 'f32'
     f32 = dec(images, masks)
+    assert auto.captions == f32.captions
     feats32 = dec.encode(images, masks)
     dec.precision = 'split_f16'
     try:
@@ -188,7 +194,7 @@ def test_precision_switch_gives_same_captions(model):
     with pytest.raises(ValueError, match='unknown precision'):
         dec.precision = 'bf16'
         dec(images, masks)
-    dec.precision = 'f32'
+    dec.precision = os.environ.get('MILAN_PRECISION', 'auto')
 
 
 def test_sample_strategy(model):

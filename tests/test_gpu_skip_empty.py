@@ -100,3 +100,68 @@ def test_float_images_are_never_skipped(ctx):
         warnings.simplefilter('ignore')
         got = ctx.encode(x, masks).cpu()
     assert torch.isnan(got[1]).all() and torch.isfinite(got[[0, 2]]).all()
+
+
+def test_full_width_trunk_kernels_read_the_count_on_the_device(dev):
+    """Round 6: how many images hold work is never read back -- every trunk launch is sized
+    for the whole batch and reads the count itself (GemmArgs::m_live).  Full-width ResNet-101
+    at 224 x 224 is where the hand-scheduled kernels run (uint8 stem, conv3_p64, chain /
+    chain3, the ping-pong tiles, persistent 128-column tiles): skipping on == off, bit for
+    bit, incl. an image count that ends inside a 256-row tile of every stage, one live
+    image, and none."""
+    sd = synthetic.resnet_state_dict('resnet101', seed=5, width=64, prefix=PREFIX)
+    c = hip.Context(hip.make_dims(sd, 10, blocks=synthetic.RESNET_BLOCKS['resnet101']), sd, dev)
+    try:
+        images, masks = synthetic.exemplars(1, k=14, size=224, seed=31, zero_every=0)
+        images, masks = images[0], masks[0].clone()
+        for precision in ('split_f16', 'f16', 'f32'):
+            c.set_precision(precision)
+            for empty in ([3, 9], [i for i in range(14) if i != 6], list(range(14))):
+                m = masks.clone()
+                m[empty] = 0
+                c.set_fusion(skip_empty=False)
+                want = c.encode(images, m).cpu()
+                c.set_fusion(skip_empty=True)
+                got = c.encode(images, m).cpu()
+                assert torch.equal(got, want), (precision, empty)
+                assert (got[empty] == 0).all()
+    finally:
+        c.close()
+
+
+def test_encode_enqueues_without_synchronising(ctx):
+    """include/milan_hip.h: "all work is enqueued on `stream`; no implicit sync".  Round 5's
+    skip-empty path read a count back (hipStreamSynchronize inside milan_encode); now the
+    whole encoder pass can be captured into a hipGraph -- a capture fails on any
+    synchronisation or read-back -- and the replay equals the eager call bit for bit."""
+    images, masks = synthetic.exemplars(4, k=3, size=64, seed=17, zero_every=0)
+    images = images.reshape(12, 3, 64, 64).cuda()
+    masks = masks.reshape(12, 1, 64, 64).clone()
+    masks[[2, 5]] = 0
+    masks = masks.cuda()
+    ctx.set_precision('split_f16')
+    ctx.set_fusion(skip_empty=True)
+    want = ctx.encode(images, masks, check=False).clone()   # (also sizes the workspace)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        ctx.encode(images, masks, check=False)
+        with torch.cuda.graph(graph, stream=side):
+            out = ctx.encode(images, masks, check=False)
+    torch.cuda.current_stream().wait_stream(side)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert (out[[2, 5]] == 0).all() and ctx.status() == 0
+    # a different set of empty masks through the SAME graph: the count is data, not a launch
+    # parameter
+    masks[[2, 5]] = 1
+    masks[[0, 7, 11]] = 0
+    graph.replay()
+    torch.cuda.synchronize()
+    ctx.set_fusion(skip_empty=False)
+    again = ctx.encode(images, masks, check=False)
+    ctx.set_fusion(skip_empty=True)
+    assert torch.equal(out, again)

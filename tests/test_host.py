@@ -567,3 +567,74 @@ def test_check_isa_pins_the_instruction_streams_of_the_ring_kernels():
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert 'kernels match' in out.stdout
+
+
+def test_check_isa_catches_a_destination_touched_before_its_wait(tmp_path):
+    """chain3 / chain / conv3 read LDS through inline asm with "=v" outputs
+    and hand-counted lgkmcnt waits; between the read and the wait that covers it the compiler
+    may copy or spill the destination.  tools/check_isa.py::pending_hazards walks the
+    disassembly with the in-order queue model and must flag exactly that -- shown on
+    deliberately broken kernels (a destination copied before the wait, a wait that allows one
+    read too many, an asm VMEM load stored before vmcnt covers it) and on their correct twin."""
+    import subprocess
+    import sys
+    hipcc = pathlib.Path('/opt/rocm/bin/hipcc')
+    if not hipcc.exists():
+        pytest.skip('no hipcc')
+    sys.path.insert(0, str(REPO / 'tools'))
+    import check_isa
+    obj = tmp_path / 'hz.o'
+    subprocess.run([str(hipcc), '--offload-arch=gfx950', '-O3', '-c',
+                    str(REPO / 'tests' / 'golden' / 'isa_hazard_cases.hip'), '-o', str(obj)],
+                   check=True, capture_output=True)
+    found = {name: check_isa.pending_hazards(lines)
+             for name, lines in check_isa.kernels(check_isa.disassemble(obj)).items()}
+    by = lambda key: next(v for k, v in found.items() if key in k)
+    assert by('hazard_good') == []
+    count, copy, vmem = by('hazard_broken_count'), by('hazard_broken_copy'), by('hazard_broken_vmem')
+    assert len(count) == 1 and count[0][0].startswith('v_add_f32') and 'ds_read_b128' in count[0][1]
+    assert len(copy) == 1 and copy[0][0].startswith('v_mov_b32') and 'ds_read_b128' in copy[0][1]
+    assert len(vmem) == 1 and vmem[0][0].startswith('global_store') and 'global_load' in vmem[0][1]
+
+
+def test_check_isa_queue_model_on_handwritten_streams():
+    """The queue model itself, on instruction streams small enough to read: in-order retire
+    by lgkmcnt(N), LDS writes counting as 'issued behind', a skipped (execz) load, a loop
+    whose back edge carries a pending read into the next iteration's first instruction."""
+    import sys
+    sys.path.insert(0, str(REPO / 'tools'))
+    import check_isa
+
+    def asm(*rows):
+        return [f'{text:<60}// {0x1000 + 4 * k:012X}: 00000000{tgt}'
+                for k, (text, tgt) in enumerate(
+                    (r if isinstance(r, tuple) else (r, '')) for r in rows)]
+
+    ok = asm('ds_read_b128 v[0:3], v8', 'ds_read_b128 v[4:7], v9', 's_waitcnt lgkmcnt(1)',
+             'v_mov_b32_e32 v10, v0', 's_waitcnt lgkmcnt(0)', 'v_mov_b32_e32 v11, v4', 's_endpgm')
+    assert check_isa.pending_hazards(ok) == []
+    # an LDS write behind the read retires it at lgkmcnt(1); a scalar load would not
+    ok2 = asm('ds_read_b128 v[0:3], v8', 'ds_write_b128 v9, v[4:7]', 's_waitcnt lgkmcnt(1)',
+              'v_mov_b32_e32 v10, v0', 's_endpgm')
+    assert check_isa.pending_hazards(ok2) == []
+    bad = asm('ds_read_b128 v[0:3], v8', 's_load_dword s4, s[0:1], 0x0', 's_waitcnt lgkmcnt(1)',
+              'v_mov_b32_e32 v10, v0', 's_endpgm')
+    assert len(check_isa.pending_hazards(bad)) == 1
+    # the load under `s_cbranch_execz` may be skipped: vmcnt(1) then does NOT cover the first one
+    skip = asm('global_load_dwordx4 v[0:3], v[8:9], off',
+               ('s_cbranch_execz 1', ' <k+0xc>'),
+               'global_load_dwordx4 v[4:7], v[10:11], off',
+               's_waitcnt vmcnt(1)', 'v_mov_b32_e32 v12, v0', 's_endpgm')
+    assert len(check_isa.pending_hazards(skip)) == 1
+    # scratch spill of a pending destination = what the allocator did to chain3 in round 5
+    spill = asm('ds_read_b128 v[0:3], v8', 'scratch_store_dwordx4 off, v[0:3], off',
+                's_waitcnt lgkmcnt(0)', 's_endpgm')
+    assert len(check_isa.pending_hazards(spill)) == 1
+    # loop: the read issued at the bottom is consumed at the top of the next trip without a wait
+    loop = asm('v_mov_b32_e32 v10, v0', 'ds_read_b128 v[0:3], v8',
+               ('s_cbranch_scc1 65533', ' <k+0x0>'), 's_waitcnt lgkmcnt(0)', 's_endpgm')
+    assert len(check_isa.pending_hazards(loop)) == 1
+    assert check_isa.scratch_in_loops(asm(
+        'scratch_load_dword v1, off, off', 'v_mov_b32_e32 v10, v0',
+        'scratch_load_dword v2, off, off', ('s_cbranch_scc1 65533', ' <k+0x4>'),
+        's_endpgm')) == ['scratch_load_dword v2, off, off']
