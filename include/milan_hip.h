@@ -36,7 +36,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MILAN_ABI_VERSION 7
+#define MILAN_ABI_VERSION 8
 
 enum {
   MILAN_OK = 0,
@@ -268,7 +268,8 @@ enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound,
                                       (round 5) */
        MILAN_FUSE_STEM = 4,
        MILAN_FUSE_CONV3 = 8,       /* layer1's 3x3 convs: weights in registers (csrc/conv3.hip) */
-       MILAN_FUSE_SKIP_EMPTY = 16 };
+       MILAN_FUSE_SKIP_EMPTY = 16,
+       MILAN_FUSE_BNECK = 32 };    /* layer1: the 3x3 conv in front of the chain launch (round 6) */
 int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);
@@ -352,7 +353,10 @@ enum milan_kernel_family {
   MILAN_KERNEL_STEM = 7,        /* stem_fused_kernel                                     */
   MILAN_KERNEL_CONV3 = 8,       /* conv3_p64_kernel                                      */
   MILAN_KERNEL_F16 = 9,         /* igemm_f16_pp32_kernel (fast mode)                     */
-  MILAN_KERNEL_COUNT = 10
+  MILAN_KERNEL_PP32T_256 = 10,  /* igemm_split16_pp32t_kernel<256>: the same tile function as
+                                   PP32_256 on k x k convs in (slice, tap, channel) order  */
+  MILAN_KERNEL_BNECK = 11,      /* chain_kernel<.., CONV>: layer1's 3x3 + expand + reduce  */
+  MILAN_KERNEL_COUNT = 12
 };
 int milan_profile_read_kernels(double* table /* [MILAN_KERNEL_COUNT][4] */);
 

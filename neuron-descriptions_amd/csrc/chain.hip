@@ -62,6 +62,10 @@ __device__ inline void chain_join8(f32x4 hi, f32x4 lo, float* v) { join8_exact(h
 
 constexpr int kSRow = 68;        // floats per row of a wave's LDS strip (64 + 4)
 constexpr int kTileFloats = 64 * 64;  // one weight tile: 64 rows x 64 k (16 KB)
+// chain_kernel<.., CONV>: pixels of the 3x3 conv's input region in LDS -- 256 output pixels
+// + (w + 1) before and after, w <= 56, rounded up to whole 4-pixel DMA pieces
+constexpr int kConvMaxW = 56;
+constexpr int kConvSlots = (256 + 2 * (kConvMaxW + 1) + 3) / 4 * 4;   // 372
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -77,7 +81,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 // like igemm_kernel<SPLIT> does for N <= 64 layers -- same bits as that kernel.
 // NR: output channels of the reduce conv: P inside a stage, 2 P when the next block opens
 // the next stage (its conv1 still runs at this stage's resolution).
-template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P>
+//
+// CONV (round 6; planes 64, 8 waves): the bottleneck's 3x3 convolution c2 runs IN FRONT of the
+// chain, in the same pixel-per-lane form -- W2 as the A operand (one 16 KB tile of the weight
+// stream per tap, nine tiles ahead of the W3 / W1 tiles, same ring, same waits), the pixels
+// of c2's input as the B operand, read from an LDS copy of the 256 + 2 (w + 1) input pixels
+// behind the workgroup's 256 consecutive output pixels (pixel p of the region at 256 p bytes,
+// its 16-byte chunks XOR-swizzled by p & 15; taps outside the image read a zero line).  The
+// accumulator of a pixel's 64 output channels then sits in the lane that owns the pixel; one
+// v_permlane32_swap per register pair turns it into whole 8-channel groups = the (hi, lo) B
+// fragments the expand product needs (after scale, + bias, ReLU, split): t2 is never
+// written and never read -- 512 bytes per pixel less through HBM, and the 3x3's MFMA work
+// runs inside a kernel whose matrix pipe is otherwise 70 % idle (conv3_p64 by itself is bound
+// by its hand-over / epilogue chain, not by HBM).  The region aliases the strips (used only
+// after it), LDS = 64 KB ring + 93 KB.  k order (tap, channel), (hl, lh, hh) per k-step and the
+// epilogue's roundings are conv3_p64's / the implicit GEMM's: same bits.
+template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P,
+          bool CONV = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
@@ -114,6 +134,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   // allowing for fewer operations than are in flight only waits a little longer.
   constexpr int C_OPS = RES_LDS ? 8 : (RES ? 10 : 2);
   static_assert(P % 64 == 0 && (NW == 4 || NW == 8), "chain: configuration");
+  static_assert(!CONV || (P == 64 && NW == 8 && !RES_LDS), "chain: the conv front needs planes 64");
+  constexpr int QC = CONV ? 9 : 0;  // weight tiles of the 3x3 conv in front of the stream
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -144,13 +166,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   const int lrow = lane >> 4;                 // row within a 4-row piece
   const int lpos = lane & 15;
   auto issue_tile = [&](int q) {
-    constexpr int NTILES = NSLAB * L;
+    constexpr int NTILES = QC + NSLAB * L;
     q = q < NTILES ? q : NTILES - 1;          // dummy re-read past the end
-    const int j = q / L, qq = q - j * L;
     const float* base;
     long ld;
-    if (qq < T3) { base = g.W3 + (long)(64 * j) * K3 + 64 * qq; ld = K3; }
-    else { base = g.W1 + (long)(64 * (qq - T3)) * N3 + 64 * j; ld = N3; }
+    if (CONV && q < QC) {
+      base = g.W2 + 64 * q; ld = 9 * 64;      // tap q: W2 rows 0..63, k 64 q ..
+    } else {
+      const int qc = q - QC;
+      const int j = qc / L, qq = qc - j * L;
+      if (qq < T3) { base = g.W3 + (long)(64 * j) * K3 + 64 * qq; ld = K3; }
+      else { base = g.W1 + (long)(64 * (qq - T3)) * N3 + 64 * j; ld = N3; }
+    }
     float* slot = ring + (q % STAGES) * kTileFloats;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
@@ -165,12 +192,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
 
   // ---- prologue: t2 fragments, first residual / bias, three tiles in flight ------
   f32x4 t2h[KS3], t2l[KS3];
+  // CONV: the input region of the 3x3 conv, pixels wg0 - (w + 1) .. wg0 + NW * 32 + w of the
+  // flat (image, y, x) list, 256 bytes each (rows beyond either end of the batch repeat the
+  // first / last row: only taps outside the image point there, and those read `czero`)
+  float* const cin = smem + STAGES * kTileFloats;           // aliases the strips
+  float* const czero = cin + kConvSlots * 64;               // 256 bytes of zeros
+  f32x4 bias2v[CONV ? 8 : 1];
+  if constexpr (CONV) {
+    const long wg0 = (long)blockIdx.x * (NW * 32);
+    const int nslots = NW * 32 + 2 * (g.cw + 1);
+    const int npieces = (nslots + 3) >> 2;
+    for (int pc = wave; pc < npieces; pc += NW) {
+      const int sl = 4 * pc + lrow;
+      long m = wg0 - (g.cw + 1) + sl;
+      m = m < 0 ? 0 : (m < g.M ? m : (long)g.M - 1);
+      const int c = lpos ^ (sl & 15);
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(g.C2in + m * 64 + c * 4),
+                                       (LDS_AS void*)(cin + pc * 256), 16, 0, 0);
+    }
+    if (tid < 16) *reinterpret_cast<f32x4*>(czero + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias of the lane's channels after the lane swap: k-step s4 = 2 t + sigma, group half
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      bias2v[2 * s4] = *reinterpret_cast<const f32x4*>(g.bias2 + 16 * s4 + 8 * half);
+      bias2v[2 * s4 + 1] = *reinterpret_cast<const f32x4*>(g.bias2 + 16 * s4 + 8 * half + 4);
+    }
+  }
   {
+    if constexpr (!CONV) {
     const float* tp = g.T2 + mfrag * P + half * 8;
 #pragma unroll
     for (int s = 0; s < P / 16; ++s) {
       t2h[s] = *reinterpret_cast<const f32x4*>(tp + s * 16);
       t2l[s] = *reinterpret_cast<const f32x4*>(tp + s * 16 + 4);
+    }
     }
     if constexpr (KD > 0) {
       const float* ap = g.A2 + mfrag * KD + half * 8;
@@ -258,8 +313,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   // the t2 fragments have landed (wait above): tell the compiler, so that it does not
   // drain the weight DMA in front of their first use inside the loop
 #pragma unroll
-  for (int s = 0; s < KS3; ++s)
+  for (int s = CONV ? P / 16 : 0; s < KS3; ++s)   // (CONV: t2 is computed below, A2 is loaded)
     asm volatile("" : "+v"(t2h[s]), "+v"(t2l[s]));
+  if constexpr (CONV) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(bias2v[s]));
+  }
 
   // weight fragments of one k-step (both 32-row MFMA tiles), double buffered: the
   // fragments of step s + 1 are fetched while step s multiplies.  With one wave per
@@ -291,6 +350,98 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   };
   load_w(ring, 0, 0);
 
+  if constexpr (CONV) {
+    // ================= 3x3 conv in front: nine weight tiles, one per tap =================
+    const int hw = g.ch * g.cw;
+    const int img = (int)(mfrag / hw);
+    const int rem = (int)(mfrag - (long)img * hw);
+    const int y = rem / g.cw, x = rem - y * g.cw;
+    // the lane's pixel inside the region (tail lanes: the clamped pixel's, a valid duplicate)
+    const int slot0 = (int)(mfrag - (long)blockIdx.x * (NW * 32)) + g.cw + 1;
+    LDS_AS const char* const cin_b = (LDS_AS const char*)cin;
+    LDS_AS const char* const czero_b = (LDS_AS const char*)czero;
+    f32x16 acc2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+    // B fragments of one k-step (hi, lo), double buffered like the weight fragments
+    f32x4 bxh[2], bxl[2];
+    LDS_AS const char* tbase = czero_b;
+    unsigned tkey = 0;
+    auto set_tap = [&](int tap) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const int yy = y + kh - 1, xx = x + kw - 1;
+      const bool ok = (unsigned)yy < (unsigned)g.ch && (unsigned)xx < (unsigned)g.cw;
+      const int sl = slot0 + (kh - 1) * g.cw + (kw - 1);
+      tkey = (unsigned)(sl & 15) << 4;
+      tbase = ok ? cin_b + sl * 256 : czero_b;
+    };
+    auto load_b = [&](int s, int buf) {
+      const unsigned ch = (unsigned)((4 * s) << 4) + ((unsigned)(2 * half) << 4);
+      bxh[buf] = *reinterpret_cast<LDS_AS const f32x4*>(tbase + (ch ^ tkey));
+      bxl[buf] = *reinterpret_cast<LDS_AS const f32x4*>(tbase + ((ch + 16u) ^ tkey));
+    };
+    set_tap(0);
+    load_b(0, 0);
+#pragma unroll
+    for (int q = 0; q < QC; ++q) {
+      issue_tile(q + AHEAD);
+      stamp(1);
+      const float* slot = ring + (q % STAGES) * kTileFloats;
+      const float* next_slot = ring + ((q + 1) % STAGES) * kTileFloats;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) {
+          load_w(slot, s + 1, (s + 1) & 1);
+          load_b(s + 1, (s + 1) & 1);
+        } else {
+          load_w(next_slot, 0, 0);
+          if (q + 1 < QC) { set_tap(q + 1); load_b(0, 0); }
+        }
+        const int b = s & 1;
+        wait_w(b);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][0]), h8(bxh[b]), acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wl[b][1]), h8(bxh[b]), acc2[1], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(bxl[b]), acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(bxl[b]), acc2[1], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(bxh[b]), acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(bxh[b]), acc2[1], 0, 0, 0);
+      }
+      stamp(2);
+      // tile q + 2 must have landed: only the pieces of tile q + 3 were issued behind it
+      if (tail) wait_vmcnt<0>();
+      else wait_vmcnt<INFL * PIECES>();
+      __builtin_amdgcn_s_barrier();
+    }
+    // ---- t2 = relu(acc2 * scale2 + bias2) as the expand product's B fragments ------------
+    // register r of tile t in lane (px, half) is channel 32 t + (r & 3) + 8 (r >> 2) + 4 half;
+    // swapping the upper half-wave of registers 8 sigma + i with the lower half-wave of
+    // registers 8 sigma + 4 + i leaves lane (px, half) with channels 32 t + 16 sigma + 8 half
+    // + 0..7 in order: k-step 2 t + sigma of the lane's pixel
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc2[t][8 * sg + i]),
+                                                    __float_as_uint(acc2[t][8 * sg + 4 + i]),
+                                                    false, false);
+          v[i] = __uint_as_float(r[0]);
+          v[4 + i] = __uint_as_float(r[1]);
+        }
+        const int s4 = 2 * t + sg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = __fmul_rn(v[e], g.scale2) + bias2v[2 * s4][e];
+          v[4 + e] = __fmul_rn(v[4 + e], g.scale2) + bias2v[2 * s4 + 1][e];
+        }
+        split8_relu_rne(v, &t2h[s4], &t2l[s4], &sat);
+      }
+  }
+
   for (int j = 0; j < NSLAB; ++j) {
     f32x16 acc3[2];
 #pragma unroll
@@ -300,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
     f32x4 xh[4], xl[4];
 #pragma unroll
     for (int qq = 0; qq < L; ++qq) {
-      const int q = j * L + qq;
+      const int q = QC + j * L + qq;
       issue_tile(q + AHEAD);
       stamp(1);
       const float* slot = ring + (q % STAGES) * kTileFloats;
@@ -503,6 +654,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
 // of a SIMD multiplied one after the other and the epilogue ran with the pipe idle).  Numbers:
 // DESIGN.md section 4.4, profiles/r3_experiments.txt, profiles/r4_experiments.txt E.
 
+bool chain_conv_supported(int P, int KD, int NR, int h, int w) {
+  return P == 64 && chain_supported(P, KD, NR) && h >= 1 && w >= 1 && w <= kConvMaxW;
+}
+
 bool chain_supported(int P, int KD, int NR) {
   if (NR == 2 * P) return KD == 0 && P == 64;  // stage boundary layer1 -> layer2
   if (NR != P) return false;
@@ -510,11 +665,16 @@ bool chain_supported(int P, int KD, int NR) {
   return P == 64 && KD == 64;
 }
 
-template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P>
+template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P,
+          bool CONV = false>
 static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
-  const size_t lds = sizeof(float) * (size_t)((RES_LDS ? 7 : 4) * kTileFloats +
-                                              NW * 32 * kSRow + (RES_LDS ? 4 * P : 0));
-  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF, NR>;
+  size_t lds = sizeof(float) * (size_t)((RES_LDS ? 7 : 4) * kTileFloats +
+                                        NW * 32 * kSRow + (RES_LDS ? 4 * P : 0));
+  if (CONV) {   // the conv's input region (+ zero line) aliases the strips
+    const size_t with_region = sizeof(float) * (size_t)(4 * kTileFloats + kConvSlots * 64 + 64);
+    lds = lds > with_region ? lds : with_region;
+  }
+  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF, NR, CONV>;
   MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   const int rows = NW * 32;
   const int grid = (a.M + rows - 1) / rows;
@@ -532,17 +692,29 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
   MILAN_REQUIRE(chain_supported(a.P, a.KD, NR) && a.M > 0, MILAN_ERR_SHAPE,
                 "chain: unsupported planes %d (+%d) -> %d", a.P, a.KD, NR);
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  MILAN_REQUIRE(al(a.T2) && al(a.W3) && al(a.bias3) && al(a.X) && al(a.W1) &&
+  const bool conv = a.C2in != nullptr;
+  MILAN_REQUIRE(!conv || (chain_conv_supported(a.P, a.KD, NR, a.ch, a.cw) && a.W2 && a.bias2 &&
+                          al(a.C2in) && al(a.W2) && al(a.bias2) && a.C2in != a.T1 &&
+                          a.M % (a.ch * a.cw) == 0),
+                MILAN_ERR_SHAPE, "chain: unsupported 3x3 front (%d x %d images)", a.ch, a.cw);
+  MILAN_REQUIRE((conv || al(a.T2)) && al(a.W3) && al(a.bias3) && al(a.X) && al(a.W1) &&
                     al(a.bias1) && al(a.T1) &&
                     (a.KD ? (a.A2 && al(a.A2) && !a.R) : (a.R && al(a.R))),
                 MILAN_ERR_SHAPE, "chain: operands must be 16-byte aligned");
   const double M = a.M, P = a.P, K3 = a.P + a.KD, R1 = NR;
+  // (conv front: + the 3x3's 2 M 64 576 flops; t2 is neither written nor read -- the operand
+  // that crosses HBM is c2's input, M x 64)
   void* rec = gemm_profile_begin(
-      2.0 * M * (4 * P) * (K3 + R1),
-      4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * R1 + 4 * P * (K3 + R1)), s);
-  profile_tag_kernel(a.P == 256 ? MILAN_KERNEL_CHAIN_WIDE : MILAN_KERNEL_CHAIN);
+      2.0 * M * (4 * P) * (K3 + R1) + (conv ? 2.0 * M * 64 * 576 : 0.0),
+      4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * R1 + 4 * P * (K3 + R1) +
+             (conv ? 64.0 * 576 : 0.0)), s);
+  profile_tag_kernel(a.P == 256 ? MILAN_KERNEL_CHAIN_WIDE
+                                : (conv ? MILAN_KERNEL_BNECK : MILAN_KERNEL_CHAIN));
   int r;
-  if (a.P == 256) r = launch_chain3(a, s);
+  if (conv && NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128, true>(a, s);
+  else if (conv && a.KD == 0) r = launch_chain_cfg<64, 8, false, 0, true, false, 64, true>(a, s);
+  else if (conv) r = launch_chain_cfg<64, 8, false, 64, true, false, 64, true>(a, s);
+  else if (a.P == 256) r = launch_chain3(a, s);
   else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);
   // the 128-channel reduce conv runs on the single-accumulator kernel when unfused
   else if (NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128>(a, s);

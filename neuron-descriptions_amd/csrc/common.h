@@ -181,8 +181,18 @@ struct ChainArgs {
   unsigned* status;      // filled by the launcher (status_word())
   const int* m_live;     // device-side row count, see GemmArgs::m_live (nullptr: M rows)
   int m_live_mul;
+  // Round 6, the bottleneck's 3x3 conv c2 IN FRONT of the chain (chain_kernel<.., CONV>; planes
+  // 64, stride 1, pad 1): when C2in != nullptr the t2 operand is not read from T2 but computed
+  // in the kernel from c2's input C2in [M][64] (pixels (img, y, x) of ch x cw images, split
+  // format) -- t2 = relu(conv3x3(C2in; W2) * scale2 + bias2) never exists in memory.
+  const float* C2in;
+  const float* W2;       // [64][576] split weights (scaled), k = tap * 64 + channel
+  const float* bias2;    // [64]
+  float scale2;          // 1 / weight scale of W2
+  int ch, cw;            // image height / width of C2in (cw <= 56)
 };
 bool chain_supported(int P, int KD, int NR = 0);
+bool chain_conv_supported(int P, int KD, int NR, int h, int w);
 int launch_chain(const ChainArgs& a, hipStream_t s);
 // ---- fused split-f16 stem (stem.hip): conv1 7x7/2 + bn1 + ReLU + maxpool 3x3/2 ----
 struct StemArgs {
@@ -454,7 +464,7 @@ struct milan_ctx {
                       // decoder, LM and the front of the trunk stay split)
   int trunk_f16 = 0;  // MILAN_PRECISION_F16: layer3 / layer4 of a bottleneck trunk on plain f16
   int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_CHAIN_WIDE | MILAN_FUSE_STEM | MILAN_FUSE_CONV3 |
-               MILAN_FUSE_SKIP_EMPTY;  // milan_set_fusion
+               MILAN_FUSE_SKIP_EMPTY | MILAN_FUSE_BNECK;  // milan_set_fusion
   // hipGraph cache of whole decode passes (milan_set_graph_capture)
   int graph_capture = 0;
   struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int seen = 0; };

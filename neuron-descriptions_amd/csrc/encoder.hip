@@ -1397,6 +1397,11 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
   // expand conv and this block's reduce conv ran as one launch (chain.hip); survives
   // the stage boundary (the last block of layer1 chains into layer2.0's conv1)
   bool t1_ready = false;
+  // c1 output of the current block.  A chain launch with the 3x3 conv in front (MILAN_FUSE_BNECK)
+  // reads it WITH its neighbours' pixels while writing the next block's, so those launches
+  // alternate between two buffers; pl.ds is free for that in split mode (every downsample
+  // conv is folded into its c3, and the fast mode borrows it from layer3 on only)
+  float *t1buf = pl.t1, *t1alt = pl.ds;
   for (int li = 0; li < 4; ++li) {
     stage.emplace(MILAN_STAGE_ENC_LAYER1 + li, s);
     const std::vector<Bottleneck>& blocks = c->blocks[li];
@@ -1457,11 +1462,11 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         h = h3; w = w3;
         continue;
       }
-      GemmArgs g1 = conv_args(b.c1, x, n, h, w, pl.t1, EPI_BIAS_RELU, nullptr,
+      GemmArgs g1 = conv_args(b.c1, x, n, h, w, t1buf, EPI_BIAS_RELU, nullptr,
                               c->zero, &h1, &w1, split);
       if (!t1_ready) MILAN_TRY(gemm_t(g1));
       t1_ready = false;
-      GemmArgs g2 = conv_args(b.c2, pl.t1, n, h1, w1, pl.t2, EPI_BIAS_RELU,
+      GemmArgs g2 = conv_args(b.c2, t1buf, n, h1, w1, pl.t2, EPI_BIAS_RELU,
                               nullptr, c->zero, &h2, &w2, split);
 #if MILAN_EXPERIMENTS
       {
@@ -1476,12 +1481,48 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         }
       }
 #endif
-      if (split && (c->fusion & MILAN_FUSE_CONV3) && b.c2.K == b.c2.Kp &&
+      // the next block: in this stage, or the first one of the next stage (its conv1
+      // is a 1x1 / stride 1 over this stage's output; the stride sits on its conv2)
+      const bool last_of_stage = bi + 1 == blocks.size();
+      const Bottleneck* nbp = !last_of_stage ? &blocks[bi + 1]
+                              : (li + 1 < 4 && !c->blocks[li + 1].empty())
+                                    ? &c->blocks[li + 1][0] : nullptr;
+      // chain launch of this block (expand conv + the next block's reduce conv): shapes
+      bool chain_plain = false, chain_ds = false;
+      int chain_P = 0, chain_NR = 0;
+      if (split && nbp != nullptr && !(fast && last_of_stage && li + 1 >= 2) && !b.basic &&
+          (c->fusion & (b.c3.cin >= 256 ? MILAN_FUSE_CHAIN_WIDE : MILAN_FUSE_CHAIN))) {
+        const Bottleneck& nb = *nbp;
+        chain_P = b.c3.cin;
+        chain_NR = last_of_stage ? 2 * chain_P : chain_P;
+        const bool shapes = !nb.basic && nb.has_down == last_of_stage && nb.c1.ws &&
+                            b.c3.ws && b.c3.kh == 1 && b.c3.kw == 1 && b.c3.stride == 1 &&
+                            b.c3.K == b.c3.Kp && b.c3.cout == 4 * chain_P &&
+                            nb.c1.kh == 1 && nb.c1.kw == 1 && nb.c1.stride == 1 &&
+                            nb.c1.cin == 4 * chain_P && nb.c1.cout == chain_NR &&
+                            nb.c1.K == nb.c1.Kp && b.c3.bias && nb.c1.bias;
+        h2 = conv_out(h1, b.c2.kh, b.c2.stride, b.c2.pad);
+        w2 = conv_out(w1, b.c2.kw, b.c2.stride, b.c2.pad);
+        chain_plain = shapes && !b.has_down && chain_supported(chain_P, 0, chain_NR);
+        chain_ds = shapes && b.has_down && b.c3d.ws && b.down.kh == 1 &&
+                   b.down.kw == 1 && b.down.stride == 1 && h2 == h &&
+                   w2 == w && chain_supported(chain_P, b.down.cin, chain_NR);
+      }
+      // round 6 (MILAN_FUSE_BNECK): layer1's 3x3 conv runs in front of that chain launch --
+      // t2 never exists in memory (chain.hip, chain_kernel<.., CONV>)
+      const bool conv_front =
+          (chain_plain || chain_ds) && (c->fusion & MILAN_FUSE_BNECK) && b.c2.K == b.c2.Kp &&
+          b.c2.bias_s && conv3_p64_supported(b.c2.cin, b.c2.cout, b.c2.kh, b.c2.kw, b.c2.stride,
+                                             b.c2.pad) &&
+          chain_conv_supported(chain_P, chain_ds ? b.down.cin : 0, chain_NR, h1, w1);
+      if (conv_front) {
+        // (nothing to launch here)
+      } else if (split && (c->fusion & MILAN_FUSE_CONV3) && b.c2.K == b.c2.Kp &&
           conv3_p64_supported(b.c2.cin, b.c2.cout, b.c2.kh, b.c2.kw, b.c2.stride,
                               b.c2.pad)) {
         // layer1's 3x3: weights in registers, input tile staged once (conv3.hip)
         Conv3Args ca{};
-        ca.in = pl.t1; ca.ws = b.c2.ws; ca.bias = b.c2.bias_s; ca.acc_scale = b.c2.ws_inv;
+        ca.in = t1buf; ca.ws = b.c2.ws; ca.bias = b.c2.bias_s; ca.acc_scale = b.c2.ws_inv;
         ca.out = pl.t2; ca.zero = c->zero; ca.n = n; ca.h = h1; ca.w = w1;
         ca.n_live = live;
         MILAN_TRY(launch_conv3_p64(ca, s));
@@ -1491,45 +1532,32 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       const float* identity = x;
       // Expand conv of this block + reduce conv of the next one in ONE launch: the
       // 4P-channel block output is written once and not read back by the next c1.
-      // the next block: in this stage, or the first one of the next stage (its conv1
-      // is a 1x1 / stride 1 over this stage's output; the stride sits on its conv2)
-      const bool last_of_stage = bi + 1 == blocks.size();
-      const Bottleneck* nbp = !last_of_stage ? &blocks[bi + 1]
-                              : (li + 1 < 4 && !c->blocks[li + 1].empty())
-                                    ? &c->blocks[li + 1][0] : nullptr;
-      if (split && nbp != nullptr && !(fast && last_of_stage && li + 1 >= 2) &&
-          (c->fusion & (b.c3.cin >= 256 ? MILAN_FUSE_CHAIN_WIDE : MILAN_FUSE_CHAIN))) {
+      if (chain_plain || chain_ds) {
         const Bottleneck& nb = *nbp;
-        const int P = b.c3.cin;
-        const int NR = last_of_stage ? 2 * P : P;
-        const bool shapes = !nb.basic && nb.has_down == last_of_stage && nb.c1.ws &&
-                            b.c3.ws && b.c3.kh == 1 && b.c3.kw == 1 && b.c3.stride == 1 &&
-                            b.c3.K == b.c3.Kp && b.c3.cout == 4 * P &&
-                            nb.c1.kh == 1 && nb.c1.kw == 1 && nb.c1.stride == 1 &&
-                            nb.c1.cin == 4 * P && nb.c1.cout == NR &&
-                            nb.c1.K == nb.c1.Kp && b.c3.bias && nb.c1.bias;
-        const bool plain = shapes && !b.has_down && chain_supported(P, 0, NR);
-        const bool with_ds = shapes && b.has_down && b.c3d.ws && b.down.kh == 1 &&
-                             b.down.kw == 1 && b.down.stride == 1 && h2 == h &&
-                             w2 == w && chain_supported(P, b.down.cin, NR);
-        if (plain || with_ds) {
-          ChainArgs ca{};
-          ca.T2 = pl.t2; ca.X = y; ca.W1 = nb.c1.ws; ca.bias1 = nb.c1.bias_s;
-          ca.T1 = pl.t1; ca.M = n * h2 * w2; ca.P = P; ca.scale1 = nb.c1.ws_inv;
-          ca.NR = NR;
-          ca.m_live = live; ca.m_live_mul = h2 * w2;
-          if (plain) {
-            ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias_s; ca.R = x; ca.scale3 = b.c3.ws_inv;
-          } else {
-            ca.W3 = b.c3d.ws; ca.bias3 = b.c3d.bias_s; ca.A2 = x; ca.KD = b.down.cin;
-            ca.scale3 = b.c3d.ws_inv;
-          }
-          MILAN_TRY(launch_chain(ca, s));
-          t1_ready = true;
-          float* tmp = x; x = y; y = tmp;
-          h = h2; w = w2;
-          continue;
+        ChainArgs ca{};
+        ca.T2 = pl.t2; ca.X = y; ca.W1 = nb.c1.ws; ca.bias1 = nb.c1.bias_s;
+        ca.T1 = t1buf; ca.M = n * h2 * w2; ca.P = chain_P; ca.scale1 = nb.c1.ws_inv;
+        ca.NR = chain_NR;
+        ca.m_live = live; ca.m_live_mul = h2 * w2;
+        if (conv_front) {
+          // c2's input is this block's t1; the next block's t1 goes to the OTHER buffer
+          // (workgroups read their neighbours' input pixels while those write their output)
+          ca.C2in = t1buf; ca.W2 = b.c2.ws; ca.bias2 = b.c2.bias_s; ca.scale2 = b.c2.ws_inv;
+          ca.ch = h1; ca.cw = w1;
+          ca.T2 = nullptr; ca.T1 = t1alt;
         }
+        if (chain_plain) {
+          ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias_s; ca.R = x; ca.scale3 = b.c3.ws_inv;
+        } else {
+          ca.W3 = b.c3d.ws; ca.bias3 = b.c3d.bias_s; ca.A2 = x; ca.KD = b.down.cin;
+          ca.scale3 = b.c3d.ws_inv;
+        }
+        MILAN_TRY(launch_chain(ca, s));
+        if (conv_front) { float* tt = t1buf; t1buf = t1alt; t1alt = tt; }
+        t1_ready = true;
+        float* tmp = x; x = y; y = tmp;
+        h = h2; w = w2;
+        continue;
       }
       if (b.has_down && split && b.c3d.ws && b.c3d.cout > 64) {
         // c3 and the downsample as ONE GEMM over [t2 | x(strided)]

@@ -2730,7 +2730,7 @@ static int launch_split16_pp32(const GemmArgs& g, hipStream_t s) {
     GemmArgs t = g;
     t.W = g.Wt;
     t.tap_inner = 1;
-    profile_tag_kernel(BNW == 256 ? MILAN_KERNEL_PP32_256 : MILAN_KERNEL_PP32_128);
+    profile_tag_kernel(BNW == 256 ? MILAN_KERNEL_PP32T_256 : MILAN_KERNEL_PP32_128);
     auto kern = igemm_split16_pp32t_kernel<BNW>;
     MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, t, tiles_m, tiles_n);

@@ -24,13 +24,13 @@ GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _R
 PRECISION_F32, PRECISION_SPLIT_F16, PRECISION_F16 = 0, 1, 2
 # 'f16' = the fast mode: narrower than the reference's fp32 (include/milan_hip.h), never a default
 PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16, 'f16': PRECISION_F16}
-FUSE_CHAIN, FUSE_CHAIN_WIDE, FUSE_STEM, FUSE_CONV3, FUSE_SKIP_EMPTY = 1, 2, 4, 8, 16  # milan_set_fusion flags (include/milan_hip.h)
+FUSE_CHAIN, FUSE_CHAIN_WIDE, FUSE_STEM, FUSE_CONV3, FUSE_SKIP_EMPTY, FUSE_BNECK = 1, 2, 4, 8, 16, 32  # milan_set_fusion flags (include/milan_hip.h)
 SKETCH_COMPACT, SKETCH_INSERT, SKETCH_MOVE, SKETCH_HALVE = 0, 1, 2, 3
 # milan_status bits (include/milan_hip.h)
 STATUS_SATURATED, STATUS_NONFINITE_INPUT = 1, 2
 # enum milan_kernel_family (milan_profile_read_kernels)
 KERNEL_FAMILIES = ('other', 'pp32_256', 'pp32_128', 'split_other', 'f32', 'chain',
-                   'chain_wide', 'stem', 'conv3', 'f16')
+                   'chain_wide', 'stem', 'conv3', 'f16', 'pp32t_256', 'bneck')
 
 
 class SketchOp(ctypes.Structure):
@@ -75,7 +75,7 @@ class Dims(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 7  # MILAN_ABI_VERSION this binding was written against
+ABI_VERSION = 8  # MILAN_ABI_VERSION this binding was written against
 
 # milan_dims.trunk_kind and the pyramid width multiplier (F = mult * width)
 TRUNK_BOTTLENECK, TRUNK_BASIC, TRUNK_ALEXNET, TRUNK_NONE = 0, 1, 2, 3
@@ -341,7 +341,8 @@ class Context:
         if os.environ.get('MILAN_CHAIN'):  # A/B timing (tools/ab_env.sh): flag bits
             bits = int(os.environ['MILAN_CHAIN'])
             self.set_fusion(chain=bool(bits & 1), wide=bool(bits & 2), stem=bool(bits & 4),
-                            conv3=bool(bits & 8), skip_empty=bool(bits & 16))
+                            conv3=bool(bits & 8), skip_empty=bool(bits & 16),
+                            bneck=bool(bits & 32))
         default = os.environ.get('MILAN_PRECISION')
         if default == 'auto':
             self.set_precision('split_f16')
@@ -386,17 +387,19 @@ class Context:
         _check(self.lib.milan_set_precision(self._h, int(precision)))
 
     def set_fusion(self, chain: bool = True, wide: Optional[bool] = None,
-                   stem: bool = True, conv3: bool = True, skip_empty: bool = True) -> None:
+                   stem: bool = True, conv3: bool = True, skip_empty: bool = True,
+                   bneck: bool = True) -> None:
         """Cross-layer fusions of the trunk (bitwise-neutral scheduling knob):
         `chain` the expand -> reduce launches of layer1 / layer2, `wide` those of
         layer3 (default: as `chain`), `stem` conv1 + bn1 + ReLU + maxpool as one launch, `conv3` the
         register-resident-weight kernel for layer1's 3x3 convolutions, `skip_empty` exemplars
-        with an all-zero mask (exact-zero features by the reference's rule) stay out of the trunk."""
+        with an all-zero mask (exact-zero features by the reference's rule) stay out of the trunk,
+        `bneck` (round 6) layer1's 3x3 conv runs in front of its chain launch (needs `chain`)."""
         wide = chain if wide is None else wide
         _check(self.lib.milan_set_fusion(
             self._h, (FUSE_CHAIN if chain else 0) | (FUSE_CHAIN_WIDE if wide else 0) |
             (FUSE_STEM if stem else 0) | (FUSE_CONV3 if conv3 else 0) |
-            (FUSE_SKIP_EMPTY if skip_empty else 0)))
+            (FUSE_SKIP_EMPTY if skip_empty else 0) | (FUSE_BNECK if bneck else 0)))
 
     @property
     def precision(self) -> str:
