@@ -299,6 +299,14 @@ class ClockPowerSampler:
                           'every 0.25 s during the timed region, rank 0\'s GPU'}
 
 
+# kernel-family key (milan_profile_read_kernels) -> rocprofv3 symbol
+SYMBOLS = {'pp32_256': 'igemm_split16_pp32_kernel', 'pp32t_256': 'igemm_split16_pp32t_kernel<256>',
+           'pp32_128': 'igemm_split16_pp32n_kernel<128> / pp32t_kernel<128>',
+           'chain_wide': 'chain3_kernel', 'chain': 'chain_kernel', 'bneck': 'chain_kernel<.., CONV>',
+           'stem': 'stem_fused_kernel', 'conv3': 'conv3_p64_kernel', 'f32': 'igemm_kernel',
+           'f16': 'igemm_f16_pp32_kernel', 'split_other': 'igemm_split16_kernel / igemm_kernel<SPLIT>'}
+
+
 def kernel_family(name):
     """rocprofv3 kernel name -> the kernel-family key of `roofline.by_kernel`
     (milan_profile_read_kernels): the ping-pong tile and its tap-inner form are ONE family."""
@@ -311,7 +319,10 @@ def kernel_family(name):
     if 'chain3_kernel' in name:
         return 'chain_wide'
     if 'chain_kernel' in name:
-        return 'chain'
+        # (template argument list ends in the CONV flag: the 3x3 conv in front, round 6)
+        import re
+        conv = re.search(r'chain_kernel<64, 8, \w+, \d+, \w+, \w+, \d+, true>', name)
+        return 'bneck' if conv else 'chain'
     if 'stem_fused' in name:
         return 'stem'
     if 'conv3_p64' in name:
@@ -652,6 +663,28 @@ def main():
         stages = hip.profile_read_stages()
         kernels = hip.profile_read_kernels()
         hip.profile_enable(False)
+        # The library prices a launch by the rows it is SIZED for; since round 6 the number of
+        # exemplars that hold work (non-empty mask) is known on the device only, so the encoder
+        # launches' algorithmic FLOPs / bytes are scaled here by the fraction this workload has
+        # (the synthetic set zeroes 1 mask in 97).
+        n_live = n_img = 0
+        for i in range(n_steps):
+            has_work = step_data[i][1][:sizes[i]].flatten(2).amax(dim=2) > 0   # (neurons, k)
+            n_live += int(has_work.sum())
+            n_img += has_work.numel()
+        live_frac = n_live / max(1, n_img)
+        for fam in ('pp32_256', 'pp32t_256', 'pp32_128', 'split_other', 'chain', 'chain_wide',
+                    'stem', 'conv3', 'bneck'):
+            if fam in kernels and fam not in ('pp32_256',):   # (pp32_256 also holds the decoder / LM products)
+                kernels[fam]['flops'] *= live_frac
+                kernels[fam]['bytes'] *= live_frac
+        # by rocprofv3 symbol (top_kernels below) ...
+        kernels_by_symbol = {k: dict(v) for k, v in kernels.items()}
+        # ... and by tile function: the ping-pong tile and its tap-inner form are ONE family
+        if 'pp32t_256' in kernels:
+            for key in ('ms', 'flops', 'launches', 'bytes'):
+                kernels['pp32_256'][key] += kernels['pp32t_256'][key]
+            del kernels['pp32t_256']
     rank_seconds = sharding.all_ranks(elapsed, device)
     rank_neurons = sharding.all_ranks(float(my_neurons), device)
     elapsed = sharding.max_over_ranks(elapsed, device)
@@ -823,6 +856,10 @@ def main():
                          f'in HBM'),
             'neurons_per_step': args.chunk,
             'neurons_total': neurons,
+            # (flat keys: the driver's parser truncates `workload` at 128 characters)
+            'k': 15, 'image_size': 224, 'trunk': 'resnet101', 'strategy': args.strategy,
+            'beam': beam, 'length': args.length, 'lambda': args.temperature, 'vocab': nv + 4,
+            'precision': args.precision,
             'parallelism': f'neuron-sharded x{world}',
             'gathered_tokens': list(all_tokens.shape),
             'gathered_tokens_sha256': hashlib.sha256(
@@ -926,6 +963,19 @@ def main():
             # the matrix cores execute 3 f16 MFMA flops per algorithmic flop
             'mfma_issue_frac': (3 * dom_achieved / peak) if split else
             dom_achieved / peak,
+            # the three launches that dominate the step BY ROCPROFV3 SYMBOL (the ping-pong tile's
+            # two kernel names apart), for a flat parser: symbol, ms per step, TF-eq, algorithmic
+            # GB per launch
+            'top_kernels': [
+                {'symbol': SYMBOLS.get(k, k), 'family': k, 'ms_per_step': v['ms'] / n_steps,
+                 'launches_per_step': v['launches'] / n_steps,
+                 'tflops_eq': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                 'frac_of_peak': v['flops'] / (v['ms'] * 1e-3) / 1e12 / peak,
+                 'algorithmic_GB_per_launch': v['bytes'] / max(1.0, v['launches']) / 1e9,
+                 'algorithmic_TBs': v['bytes'] / (v['ms'] * 1e-3) / 1e12}
+                for k, v in sorted(kernels_by_symbol.items(), key=lambda kv: -kv[1]['ms'])[:3]
+                if v['ms'] > 0],
+            'live_image_fraction': live_frac,
             'by_kernel': {k: {'ms_per_step': v['ms'] / n_steps,
                               'launches_per_step': v['launches'] / n_steps,
                               'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,

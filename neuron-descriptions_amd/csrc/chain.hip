@@ -387,7 +387,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
 #pragma unroll
     for (int q = 0; q < QC; ++q) {
       issue_tile(q + AHEAD);
-      stamp(1);
       const float* slot = ring + (q % STAGES) * kTileFloats;
       const float* next_slot = ring + ((q + 1) % STAGES) * kTileFloats;
 #pragma unroll
@@ -408,7 +407,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
         acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][0]), h8(bxh[b]), acc2[0], 0, 0, 0);
         acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(wh[b][1]), h8(bxh[b]), acc2[1], 0, 0, 0);
       }
-      stamp(2);
       // tile q + 2 must have landed: only the pieces of tile q + 3 were issued behind it
       if (tail) wait_vmcnt<0>();
       else wait_vmcnt<INFL * PIECES>();
@@ -440,6 +438,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
         }
         split8_relu_rne(v, &t2h[s4], &t2l[s4], &sat);
       }
+    stamp(7);   // (in-kernel profile: the whole 3x3 phase)
   }
 
   for (int j = 0; j < NSLAB; ++j) {
@@ -711,6 +710,11 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
   profile_tag_kernel(a.P == 256 ? MILAN_KERNEL_CHAIN_WIDE
                                 : (conv ? MILAN_KERNEL_BNECK : MILAN_KERNEL_CHAIN));
   int r;
+#if MILAN_EXPERIMENTS
+  if (conv && a.KD == 0 && NR == 64 && a.prof)   // in-kernel phase profile (tools/bench/bneckbench.hip)
+    r = launch_chain_cfg<64, 8, false, 0, true, true, 64, true>(a, s);
+  else
+#endif
   if (conv && NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128, true>(a, s);
   else if (conv && a.KD == 0) r = launch_chain_cfg<64, 8, false, 0, true, false, 64, true>(a, s);
   else if (conv) r = launch_chain_cfg<64, 8, false, 64, true, false, 64, true>(a, s);

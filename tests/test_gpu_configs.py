@@ -297,7 +297,7 @@ def test_config5_replicated_64k_shard_beam50(world):
     assert len(caps) == n
     for rep in range(1, n // base):
         assert list(caps[rep * base:(rep + 1) * base]) == list(caps[:base]), rep
-    idx = subset_indices(16)
+    idx = subset_indices(base)   # 32 neurons: the first and the last batch-of-16 of the base set
     check_subset(caps, oracle_subset(images, masks, sd, idx, 'rerank', 50, 16))
 
 
