@@ -96,8 +96,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 // by its hand-over / epilogue chain, not by HBM).  The region aliases the strips (used only
 // after it), LDS = 64 KB ring + 93 KB.  k order (tap, channel), (hl, lh, hh) per k-step and the
 // epilogue's roundings are conv3_p64's / the implicit GEMM's: same bits.
+//
+// C1 (with CONV; layer1.0, 64-channel block input): the block's own 1x1 reduce conv runs in
+// front of the 3x3 -- the region is DMA'd from the block INPUT, one more 16 KB tile (W0) heads
+// the weight stream, and before the first tap every wave turns one or two 32-pixel blocks of
+// the region into t1 = relu(x W0^T * scale0 + bias0) IN PLACE (fragments out of the region,
+// 24 MFMAs, lane swap, split, eight 16-byte writes back into the pixel's own slots; with the
+// separate cross-term accumulator of igemm_kernel<SPLIT>, the kernel that runs this layer
+// unfused -- same bits).  Halo pixels are computed by every workgroup that needs them (1.45 x
+// of a 64 x 64 product).  The whole bottleneck in one launch: t1 and t2 stay on chip.
 template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P,
-          bool CONV = false>
+          bool CONV = false, bool C1 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = 0;
@@ -135,7 +144,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   constexpr int C_OPS = RES_LDS ? 8 : (RES ? 10 : 2);
   static_assert(P % 64 == 0 && (NW == 4 || NW == 8), "chain: configuration");
   static_assert(!CONV || (P == 64 && NW == 8 && !RES_LDS), "chain: the conv front needs planes 64");
-  constexpr int QC = CONV ? 9 : 0;  // weight tiles of the 3x3 conv in front of the stream
+  static_assert(!C1 || CONV, "chain: c1 in front needs the conv front");
+  constexpr int Q1 = C1 ? 1 : 0;       // weight tile of the block's own c1 at the very front
+  constexpr int QC = CONV ? 9 + Q1 : 0;  // ... then the nine taps of the 3x3 conv
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -170,8 +181,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
     q = q < NTILES ? q : NTILES - 1;          // dummy re-read past the end
     const float* base;
     long ld;
-    if (CONV && q < QC) {
-      base = g.W2 + 64 * q; ld = 9 * 64;      // tap q: W2 rows 0..63, k 64 q ..
+    if (C1 && q == 0) {
+      base = g.W0; ld = 64;                   // c1: W0 rows 0..63, k 0..63
+    } else if (CONV && q < QC) {
+      base = g.W2 + 64 * (q - Q1); ld = 9 * 64;   // tap q - Q1: W2 rows 0..63, k 64 tap ..
     } else {
       const int qc = q - QC;
       const int j = qc / L, qq = qc - j * L;
@@ -197,7 +210,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
   // first / last row: only taps outside the image point there, and those read `czero`)
   float* const cin = smem + STAGES * kTileFloats;           // aliases the strips
   float* const czero = cin + kConvSlots * 64;               // 256 bytes of zeros
-  f32x4 bias2v[CONV ? 8 : 1];
+  f32x4 bias2v[CONV ? 8 : 1], bias0v[C1 ? 8 : 1];
+  if constexpr (C1) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      bias0v[2 * s4] = *reinterpret_cast<const f32x4*>(g.bias0 + 16 * s4 + 8 * half);
+      bias0v[2 * s4 + 1] = *reinterpret_cast<const f32x4*>(g.bias0 + 16 * s4 + 8 * half + 4);
+    }
+  }
   if constexpr (CONV) {
     const long wg0 = (long)blockIdx.x * (NW * 32);
     const int nslots = NW * 32 + 2 * (g.cw + 1);
@@ -319,6 +339,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(bias2v[s]));
   }
+  if constexpr (C1) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(bias0v[s]));
+  }
 
   // weight fragments of one k-step (both 32-row MFMA tiles), double buffered: the
   // fragments of step s + 1 are fetched while step s multiplies.  With one wave per
@@ -382,10 +406,81 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
       bxh[buf] = *reinterpret_cast<LDS_AS const f32x4*>(tbase + (ch ^ tkey));
       bxl[buf] = *reinterpret_cast<LDS_AS const f32x4*>(tbase + ((ch + 16u) ^ tkey));
     };
+    if constexpr (C1) {
+      // ============ the block's own c1 over the whole region, in place (tile 0 = W0) ============
+      issue_tile(AHEAD);
+      const int nslots = NW * 32 + 2 * (g.cw + 1);
+      const int nblk = (nslots + 31) >> 5;
+      const float* w0 = ring;   // (slot 0 of the ring)
+      for (int blk = wave; blk < nblk; blk += NW) {
+        int sl = 32 * blk + px;
+        const bool own = sl < nslots;           // (the last block reaches beyond the region:
+        sl = own ? sl : nslots - 1;             //  those lanes repeat its last pixel, unstored)
+        LDS_AS char* const pb = (LDS_AS char*)cin + sl * 256;
+        const unsigned key = (unsigned)(sl & 15) << 4;
+        f32x4 xh[4], xl[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const unsigned ch = (unsigned)((4 * s + 2 * half) << 4);
+          xh[s] = *reinterpret_cast<LDS_AS const f32x4*>(pb + (ch ^ key));
+          xl[s] = *reinterpret_cast<LDS_AS const f32x4*>(pb + ((ch + 16u) ^ key));
+        }
+        // (one 32-channel tile at a time: two accumulators of 16 registers live, not four)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x16 a0, a0x;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a0x[r] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const f32x4 ah = wfrag(w0, t, 4 * s + 2 * half);
+            const f32x4 al = wfrag(w0, t, 4 * s + 2 * half + 1);
+            // (hh in one accumulator, hl + lh in the other: igemm_kernel<SPLIT>'s order)
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah), h8(xh[s]), a0, 0, 0, 0);
+            a0x = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al), h8(xh[s]), a0x, 0, 0, 0);
+            a0x = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah), h8(xl[s]), a0x, 0, 0, 0);
+          }
+          a0 = a0 + a0x;
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0[8 * sg + i]),
+                                                        __float_as_uint(a0[8 * sg + 4 + i]),
+                                                        false, false);
+              v[i] = __uint_as_float(r[0]);
+              v[4 + i] = __uint_as_float(r[1]);
+            }
+            const int s4 = 2 * t + sg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = __fmul_rn(v[e], g.scale0) + bias0v[2 * s4][e];
+              v[4 + e] = __fmul_rn(v[4 + e], g.scale0) + bias0v[2 * s4 + 1][e];
+            }
+            f32x4 hi, lo;
+            split8_relu_rne(v, &hi, &lo, &sat);
+            // the lane's 8-channel group 2 s4 + half of its pixel: chunks 2 g, 2 g + 1
+            const unsigned ch = (unsigned)((4 * s4 + 2 * half) << 4);
+            if (own) {
+              *reinterpret_cast<LDS_AS f32x4*>(pb + (ch ^ key)) = hi;
+              *reinterpret_cast<LDS_AS f32x4*>(pb + ((ch + 16u) ^ key)) = lo;
+            }
+          }
+        }
+      }
+      // tile 2 has landed (only the pieces of tile 3 were issued behind it); every wave's
+      // region writes are done before the first tap reads them
+      if (tail) wait_vmcnt<0>();
+      else wait_vmcnt<INFL * PIECES>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      load_w(ring + (Q1 % STAGES) * kTileFloats, 0, 0);
+    }
     set_tap(0);
     load_b(0, 0);
 #pragma unroll
-    for (int q = 0; q < QC; ++q) {
+    for (int q = Q1; q < QC; ++q) {
       issue_tile(q + AHEAD);
       const float* slot = ring + (q % STAGES) * kTileFloats;
       const float* next_slot = ring + ((q + 1) % STAGES) * kTileFloats;
@@ -396,7 +491,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void chain_kernel(ChainArgs g) {
           load_b(s + 1, (s + 1) & 1);
         } else {
           load_w(next_slot, 0, 0);
-          if (q + 1 < QC) { set_tap(q + 1); load_b(0, 0); }
+          if (q + 1 < QC) { set_tap(q + 1 - Q1); load_b(0, 0); }
         }
         const int b = s & 1;
         wait_w(b);
@@ -657,6 +752,10 @@ bool chain_conv_supported(int P, int KD, int NR, int h, int w) {
   return P == 64 && chain_supported(P, KD, NR) && h >= 1 && w >= 1 && w <= kConvMaxW;
 }
 
+bool chain_conv_c1_supported(int P, int KD, int NR, int h, int w) {
+  return chain_conv_supported(P, KD, NR, h, w) && KD == 64 && NR == 64;   // layer1.0
+}
+
 bool chain_supported(int P, int KD, int NR) {
   if (NR == 2 * P) return KD == 0 && P == 64;  // stage boundary layer1 -> layer2
   if (NR != P) return false;
@@ -665,7 +764,7 @@ bool chain_supported(int P, int KD, int NR) {
 }
 
 template <int P, int NW, bool RES_LDS, int KD, bool XACC, bool PROF = false, int NR = P,
-          bool CONV = false>
+          bool CONV = false, bool C1 = false>
 static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
   size_t lds = sizeof(float) * (size_t)((RES_LDS ? 7 : 4) * kTileFloats +
                                         NW * 32 * kSRow + (RES_LDS ? 4 * P : 0));
@@ -673,7 +772,7 @@ static int launch_chain_cfg(const ChainArgs& a, hipStream_t s) {
     const size_t with_region = sizeof(float) * (size_t)(4 * kTileFloats + kConvSlots * 64 + 64);
     lds = lds > with_region ? lds : with_region;
   }
-  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF, NR, CONV>;
+  auto kern = chain_kernel<P, NW, RES_LDS, KD, XACC, PROF, NR, CONV, C1>;
   MILAN_TRY(ensure_lds_attr(reinterpret_cast<const void*>(kern), (int)lds));
   const int rows = NW * 32;
   const int grid = (a.M + rows - 1) / rows;
@@ -696,6 +795,10 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
                           al(a.C2in) && al(a.W2) && al(a.bias2) && a.C2in != a.T1 &&
                           a.M % (a.ch * a.cw) == 0),
                 MILAN_ERR_SHAPE, "chain: unsupported 3x3 front (%d x %d images)", a.ch, a.cw);
+  const bool c1 = conv && a.W0 != nullptr;
+  MILAN_REQUIRE(!c1 || (chain_conv_c1_supported(a.P, a.KD, NR, a.ch, a.cw) && a.bias0 && al(a.W0) &&
+                        al(a.bias0)),
+                MILAN_ERR_SHAPE, "chain: unsupported c1 front");
   MILAN_REQUIRE((conv || al(a.T2)) && al(a.W3) && al(a.bias3) && al(a.X) && al(a.W1) &&
                     al(a.bias1) && al(a.T1) &&
                     (a.KD ? (a.A2 && al(a.A2) && !a.R) : (a.R && al(a.R))),
@@ -704,7 +807,7 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
   // (conv front: + the 3x3's 2 M 64 576 flops; t2 is neither written nor read -- the operand
   // that crosses HBM is c2's input, M x 64)
   void* rec = gemm_profile_begin(
-      2.0 * M * (4 * P) * (K3 + R1) + (conv ? 2.0 * M * 64 * 576 : 0.0),
+      2.0 * M * (4 * P) * (K3 + R1) + (conv ? 2.0 * M * 64 * 576 : 0.0) + (c1 ? 2.0 * M * 64 * 64 : 0.0),
       4.0 * (M * K3 + M * 4 * P * (a.KD ? 1 : 2) + M * R1 + 4 * P * (K3 + R1) +
              (conv ? 64.0 * 576 : 0.0)), s);
   profile_tag_kernel(a.P == 256 ? MILAN_KERNEL_CHAIN_WIDE
@@ -717,6 +820,7 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
 #endif
   if (conv && NR == 128) r = launch_chain_cfg<64, 8, false, 0, false, false, 128, true>(a, s);
   else if (conv && a.KD == 0) r = launch_chain_cfg<64, 8, false, 0, true, false, 64, true>(a, s);
+  else if (c1) r = launch_chain_cfg<64, 8, false, 64, true, false, 64, true, true>(a, s);
   else if (conv) r = launch_chain_cfg<64, 8, false, 64, true, false, 64, true>(a, s);
   else if (a.P == 256) r = launch_chain3(a, s);
   else if (a.P == 128) r = launch_chain_cfg<128, 8, false, 0, false>(a, s);

@@ -190,9 +190,17 @@ struct ChainArgs {
   const float* bias2;    // [64]
   float scale2;          // 1 / weight scale of W2
   int ch, cw;            // image height / width of C2in (cw <= 56)
+  // ... and the block's OWN 1x1 reduce conv c1 in front of that (chain_kernel<.., CONV, C1>;
+  // layer1.0, whose input has 64 channels): when W0 != nullptr, C2in is the BLOCK INPUT x
+  // [M][64] and t1 = relu(x W0^T * scale0 + bias0) is computed in place in the LDS copy of
+  // the input region -- neither t1 nor t2 exists in memory (the whole bottleneck in one launch).
+  const float* W0;       // [64][64] split weights (scaled)
+  const float* bias0;    // [64]
+  float scale0;
 };
 bool chain_supported(int P, int KD, int NR = 0);
 bool chain_conv_supported(int P, int KD, int NR, int h, int w);
+bool chain_conv_c1_supported(int P, int KD, int NR, int h, int w);
 int launch_chain(const ChainArgs& a, hipStream_t s);
 // ---- fused split-f16 stem (stem.hip): conv1 7x7/2 + bn1 + ReLU + maxpool 3x3/2 ----
 struct StemArgs {

@@ -1464,7 +1464,9 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
       }
       GemmArgs g1 = conv_args(b.c1, x, n, h, w, t1buf, EPI_BIAS_RELU, nullptr,
                               c->zero, &h1, &w1, split);
-      if (!t1_ready) MILAN_TRY(gemm_t(g1));
+      // (MILAN_FUSE_BNECK, layer1.0: c1 may run inside the block's chain launch -- decided below,
+      // once the launch's shape is known)
+      const bool c1_pending = !t1_ready;
       t1_ready = false;
       GemmArgs g2 = conv_args(b.c2, t1buf, n, h1, w1, pl.t2, EPI_BIAS_RELU,
                               nullptr, c->zero, &h2, &w2, split);
@@ -1515,6 +1517,14 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
           b.c2.bias_s && conv3_p64_supported(b.c2.cin, b.c2.cout, b.c2.kh, b.c2.kw, b.c2.stride,
                                              b.c2.pad) &&
           chain_conv_supported(chain_P, chain_ds ? b.down.cin : 0, chain_NR, h1, w1);
+      // ... and for the stage's first block (64-channel input, no t1 yet) the block's own c1
+      // as well: the whole bottleneck in one launch (chain_kernel<.., CONV, C1>)
+      const bool c1_front =
+          conv_front && c1_pending && chain_ds && b.c1.ws && b.c1.bias_s && b.c1.kh == 1 &&
+          b.c1.kw == 1 && b.c1.stride == 1 && b.c1.cin == 64 && b.c1.cout == 64 &&
+          b.c1.K == b.c1.Kp && h1 == h && w1 == w &&
+          chain_conv_c1_supported(chain_P, b.down.cin, chain_NR, h1, w1);
+      if (c1_pending && !c1_front) MILAN_TRY(gemm_t(g1));
       if (conv_front) {
         // (nothing to launch here)
       } else if (split && (c->fusion & MILAN_FUSE_CONV3) && b.c2.K == b.c2.Kp &&
@@ -1545,6 +1555,9 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
           ca.C2in = t1buf; ca.W2 = b.c2.ws; ca.bias2 = b.c2.bias_s; ca.scale2 = b.c2.ws_inv;
           ca.ch = h1; ca.cw = w1;
           ca.T2 = nullptr; ca.T1 = t1alt;
+          if (c1_front) {   // the region is the block INPUT; t1 is made in LDS
+            ca.C2in = x; ca.W0 = b.c1.ws; ca.bias0 = b.c1.bias_s; ca.scale0 = b.c1.ws_inv;
+          }
         }
         if (chain_plain) {
           ca.W3 = b.c3.ws; ca.bias3 = b.c3.bias_s; ca.R = x; ca.scale3 = b.c3.ws_inv;

@@ -61,14 +61,16 @@ PINNED = {
     'igemm_split16_pp32t_kernelILi128': {'mfma': 288, 'lds_dma': 84, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4], 'scratch_in_loops': 0, 'hazards': 0},
     'igemm_f16_pp32_kernelILi256ELb1': {'mfma': 384, 'lds_dma': 112, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4], 'scratch_in_loops': 0, 'hazards': 0},
     'igemm_f16_pp32_kernelILi128ELb1': {'mfma': 192, 'lds_dma': 84, 'global_load_x4': 0, 'global_store_x4': 0, 'barriers': 52, 'scratch': 0, 'vmcnt': [0, 4], 'scratch_in_loops': 0, 'hazards': 0},
-    'chain_kernelILi128ELi8ELb0ELi0ELb0ELb0ELi128ELb0': {'mfma': 96, 'lds_dma': 14, 'global_load_x4': 40, 'global_store_x4': 24, 'barriers': 6, 'scratch': 6, 'vmcnt': [0, 1, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
-    'chain_kernelILi64ELi8ELb0ELi0ELb1ELb0ELi64ELb0': {'mfma': 48, 'lds_dma': 10, 'global_load_x4': 30, 'global_store_x4': 16, 'barriers': 4, 'scratch': 0, 'vmcnt': [0, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
-    'chain_kernelILi64ELi8ELb0ELi64ELb1ELb0ELi64ELb0': {'mfma': 72, 'lds_dma': 12, 'global_load_x4': 22, 'global_store_x4': 16, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 2, 4], 'scratch_in_loops': 0, 'hazards': 0},
-    'chain_kernelILi64ELi8ELb0ELi0ELb0ELb0ELi128ELb0': {'mfma': 72, 'lds_dma': 12, 'global_load_x4': 32, 'global_store_x4': 24, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 1, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
+    'chain_kernelILi128ELi8ELb0ELi0ELb0ELb0ELi128ELb0ELb0': {'mfma': 96, 'lds_dma': 14, 'global_load_x4': 40, 'global_store_x4': 24, 'barriers': 6, 'scratch': 6, 'vmcnt': [0, 1, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
+    'chain_kernelILi64ELi8ELb0ELi0ELb1ELb0ELi64ELb0ELb0': {'mfma': 48, 'lds_dma': 10, 'global_load_x4': 30, 'global_store_x4': 16, 'barriers': 4, 'scratch': 0, 'vmcnt': [0, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
+    'chain_kernelILi64ELi8ELb0ELi64ELb1ELb0ELi64ELb0ELb0': {'mfma': 72, 'lds_dma': 12, 'global_load_x4': 22, 'global_store_x4': 16, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 2, 4], 'scratch_in_loops': 0, 'hazards': 0},
+    'chain_kernelILi64ELi8ELb0ELi0ELb0ELb0ELi128ELb0ELb0': {'mfma': 72, 'lds_dma': 12, 'global_load_x4': 32, 'global_store_x4': 24, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 1, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
     # round 6: the same chains with layer1's 3x3 conv in front (chain_kernel<.., CONV>)
-    'chain_kernelILi64ELi8ELb0ELi0ELb1ELb0ELi64ELb1': {'mfma': 264, 'lds_dma': 29, 'global_load_x4': 30, 'global_store_x4': 16, 'barriers': 13, 'scratch': 0, 'vmcnt': [0, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
-    'chain_kernelILi64ELi8ELb0ELi64ELb1ELb0ELi64ELb1': {'mfma': 288, 'lds_dma': 31, 'global_load_x4': 22, 'global_store_x4': 16, 'barriers': 14, 'scratch': 0, 'vmcnt': [0, 2, 4], 'scratch_in_loops': 0, 'hazards': 0},
-    'chain_kernelILi64ELi8ELb0ELi0ELb0ELb0ELi128ELb1': {'mfma': 288, 'lds_dma': 31, 'global_load_x4': 32, 'global_store_x4': 24, 'barriers': 14, 'scratch': 0, 'vmcnt': [0, 1, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
+    'chain_kernelILi64ELi8ELb0ELi0ELb1ELb0ELi64ELb1ELb0': {'mfma': 264, 'lds_dma': 29, 'global_load_x4': 30, 'global_store_x4': 16, 'barriers': 13, 'scratch': 0, 'vmcnt': [0, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
+    'chain_kernelILi64ELi8ELb0ELi64ELb1ELb0ELi64ELb1ELb0': {'mfma': 288, 'lds_dma': 31, 'global_load_x4': 22, 'global_store_x4': 16, 'barriers': 14, 'scratch': 0, 'vmcnt': [0, 2, 4], 'scratch_in_loops': 0, 'hazards': 0},
+    'chain_kernelILi64ELi8ELb0ELi0ELb0ELb0ELi128ELb1ELb0': {'mfma': 288, 'lds_dma': 31, 'global_load_x4': 32, 'global_store_x4': 24, 'barriers': 14, 'scratch': 0, 'vmcnt': [0, 1, 2, 12], 'scratch_in_loops': 0, 'hazards': 0},
+    # ... and with the block's own c1 in front as well (layer1.0: the whole bottleneck)
+    'chain_kernelILi64ELi8ELb0ELi64ELb1ELb0ELi64ELb1ELb1': {'mfma': 312, 'lds_dma': 33, 'global_load_x4': 30, 'global_store_x4': 16, 'barriers': 15, 'scratch': 0, 'vmcnt': [0, 2, 4], 'scratch_in_loops': 0, 'hazards': 0},
     'conv3_p64_kernel': {'mfma': 162, 'lds_dma': 20, 'global_load_x4': 36, 'global_store_x4': 4, 'barriers': 5, 'scratch': 0, 'vmcnt': [0, 5], 'scratch_in_loops': 0, 'hazards': 0},
     'stem_fused_kernelILi7ELi8ELi8ELb0': {'mfma': 84, 'lds_dma': 6, 'global_load_x4': 33, 'global_store_x4': 10, 'barriers': 3, 'scratch': 6, 'vmcnt': [0], 'scratch_in_loops': 3, 'hazards': 0},
     'stem_fused_kernelILi7ELi8ELi8ELb1': {'mfma': 84, 'lds_dma': 0, 'global_load_x4': 33, 'global_store_x4': 10, 'barriers': 5, 'scratch': 8, 'vmcnt': [0], 'scratch_in_loops': 4, 'hazards': 0},
