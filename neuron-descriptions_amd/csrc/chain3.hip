@@ -138,6 +138,11 @@ __global__ __launch_bounds__(512, 2) void chain3_kernel(ChainArgs g, int ntiles)
   int tile = blockIdx.x;
   int qbase = 0;
 
+  // (Registers: 254 of 256.  The build keeps 4 scratch operations -- a two-register spill whose
+  // store / reload sit on the persistent tile loop, once per tile, none inside the slab loop;
+  // tools/check_isa.py pins them and fails on any scratch operation inside a further loop.
+  // Every vmcnt(N) below is derived WITHOUT counting stores or scratch traffic: both can only
+  // make a wait longer than needed, never shorter.)
   // ---- weight-pair DMA ----------------------------------------------------------------
   // A pair = two 16 KB tiles (64 weight rows x 64 k, 256-byte LDS rows, 16-byte chunk c of
   // row r at position c ^ (r & 15)).  A wave of the issuing group moves pieces i = 0..3 of

@@ -16,6 +16,6 @@ print("kernel,calls,total_ms,avg_us,min_us,max_us,pct")
 for r in db.execute("select name,count(*),sum(end-start)/1e6,avg(end-start)/1e3,min(end-start)/1e3,max(end-start)/1e3,100.0*sum(end-start)/%d from kernels group by name order by 3 desc" % tot):
     print('"%s",%d,%.2f,%.1f,%.1f,%.1f,%.2f' % (r[0][:110],r[1],r[2],r[3],r[4],r[5],r[6]))
 PY
-# (last argument 2: the layer3 chains of csrc/chain3.hip are on, round 5)
-python tools/layer_report.py $f 9600 17 1 2 > gpurun_out/layer_report.txt
+# (last argument 3: layer3 chains of csrc/chain3.hip + layer1 conv front, round 6)
+python tools/layer_report.py $f 9600 17 1 3 > gpurun_out/layer_report.txt
 tail -1 /tmp/prof_bench.json | cut -c1-300

@@ -1,6 +1,7 @@
 """Per-layer GEMM throughput from a rocprofv3 rocpd database of bench.py.
 
-usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3] [fused_ds=0|1] [chain=0|1]
+usage: python tools/layer_report.py <bench_results.db> [n_images=3840] [passes=3] [fused_ds=0|1] [chain=0|1|2|3]
+(chain=2: + the layer3 chains of csrc/chain3.hip; 3: + layer1's 3x3 / c1 in front of its chain launches, round 6)
 chain=1 (round 3): a bottleneck's expand conv c3 and the next bottleneck's reduce conv
 c1 are ONE launch (csrc/chain.hip) wherever the next block has no downsample branch and
 the stage is layer1..3; such pairs are reported as `lX.x.c3>c1`.  The fused stem
@@ -20,7 +21,7 @@ GEMM_LIKE = ("name like '%igemm%' or name like '%conv3x3%' or name like '%chain_
              "or name like '%stem_fused%' or name like '%conv3_p64%'")
 
 
-def build_layers(n, fused, chain, wide):
+def build_layers(n, fused, chain, wide, bneck=False):
     """(name, M, N, K, flops) of the encoder's GEMM-class launches of one pass of n
     images, in launch order (ResNet-101, split-f16 mode)."""
     layers = []
@@ -39,17 +40,30 @@ def build_layers(n, fused, chain, wide):
         pl = 64 * 2**li
         for bi in range(nb):
             s = 2 if (bi == 0 and li > 0) else 1
-            if not chained_c1:
-                conv(f'l{li+1}.{bi}.c1', h, inp, pl, 1, 1)
-            h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
             # chain.hip: planes <= 256, a next block in the stage; block 0 (two-source
             # expand) only where its downsample has stride 1 (layer1)
             # ... or, for planes 64, the first block of the next stage (its c1 has 2 x
             # the planes and runs at this stage's resolution)
             boundary = chain and bi + 1 == nb and pl == 64
-            chained_c1 = boundary or (
+            will_chain = boundary or (
                 chain and pl <= (256 if wide else 128) and bi + 1 < nb and
                 (bi > 0 or (fused and li == 0)))
+            # round 6 (MILAN_FUSE_BNECK): layer1's 3x3 conv -- and layer1.0's own c1 -- run
+            # inside the block's chain launch
+            front = bneck and will_chain and pl == 64
+            front_c1 = front and bi == 0 and not chained_c1
+            extra = 0
+            if not chained_c1:
+                if front_c1:
+                    extra += 2 * n * h * h * pl * inp
+                else:
+                    conv(f'l{li+1}.{bi}.c1', h, inp, pl, 1, 1)
+            if front:
+                h2 = (h + 2 - 3) // s + 1
+                extra += 2 * n * h2 * h2 * pl * 9 * pl
+            else:
+                h2 = conv(f'l{li+1}.{bi}.c2', h, pl, pl, 3, s)
+            chained_c1 = will_chain
             tag = f'l{li+1}.{bi}.'
             if chained_c1:
                 m = n * h2 * h2
@@ -57,8 +71,10 @@ def build_layers(n, fused, chain, wide):
                 nr = 2 * pl if boundary else pl
                 name = tag + ('c3+ds>c1' if bi == 0 else
                               f'c3>l{li+2}.0.c1' if boundary else 'c3>c1')
+                if front:
+                    name = tag + ('c1>c2>' if front_c1 else 'c2>') + name[len(tag):]
                 layers.append((name, m, pl * 4, k3 + nr,
-                               2 * m * pl * 4 * k3 + 2 * m * nr * pl * 4))
+                               2 * m * pl * 4 * k3 + 2 * m * nr * pl * 4 + extra))
             elif bi == 0 and not fused:
                 conv(tag + 'ds', h, inp, pl * 4, 1, s)
                 conv(tag + 'c3', h2, pl, pl * 4, 1, 1)
@@ -80,14 +96,15 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
     passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     fused = len(sys.argv) > 4 and sys.argv[4] == '1'  # split mode: ds folded into c3
-    chain = len(sys.argv) > 5 and sys.argv[5] in ("1", "2")
-    wide = len(sys.argv) > 5 and sys.argv[5] == "2"  # layer3 chains on too
+    chain = len(sys.argv) > 5 and sys.argv[5] in ("1", "2", "3")
+    wide = len(sys.argv) > 5 and sys.argv[5] in ("2", "3")  # layer3 chains on too
+    bneck = len(sys.argv) > 5 and sys.argv[5] == "3"        # round 6: layer1's conv front
     rows = db.execute(
         "select name, start, end-start, grid_x from kernels where " + GEMM_LIKE +
         " order by start").fetchall()
     per = len(rows) // passes
     rows = rows[per * (passes - 1):]
-    layers = build_layers(n, fused, chain, wide)
+    layers = build_layers(n, fused, chain, wide, bneck)
     agg, tot_t, tot_f = {}, 0, 0
     for (name, m, nn, k, fl), (_, _, du, _) in zip(layers, rows):
         key = group_key(name)

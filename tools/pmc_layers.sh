@@ -34,7 +34,7 @@ def load(c):
     return rows
 F, W = load('FETCH_SIZE'), load('WRITE_SIZE')
 n = 3840
-layers = build_layers(n, True, True, True)  # split mode: folded downsamples, layer1/2/3 chains
+layers = build_layers(n, True, True, True, True)  # split mode: folded downsamples, layer1/2/3 chains, layer1 conv front
 agg = {}
 for (name, m, nn, k, fl), f, w in zip(layers, F, W):
     a = agg.setdefault(group_key(name), [0, 0.0, 0.0, m, nn, k, f[1][:40]])
