@@ -147,6 +147,12 @@ unsigned* status_word();
 // kernel family of the GEMM-class launch being recorded (milan_profile_read_kernels)
 void profile_tag_kernel(int family);
 // rows x K fp32 (row stride ld_src) -> split format (row stride ld_dst), x scale
+// Zero `bytes` (a multiple of 4, 4-byte aligned) on the stream with a KERNEL.  Not
+// hipMemsetAsync: as a node of a captured graph (round 6: whole passes can be captured) the
+// runtime's fill replayed a recycled 16-byte pattern from the second replay on (ROCm 7.2; the
+// feature rows of empty-mask exemplars and the LM's initial state came back as garbage:
+// tools/graph_describe.py, tests/test_gpu_skip_empty.py).
+int launch_zero_fill(void* p, size_t bytes, hipStream_t s);
 int launch_f32_to_split(const float* src, long ld_src, float* dst, long ld_dst,
                         long rows, int K, float scale, hipStream_t s);
 int gemm_profile_enable(int enable);

@@ -1673,10 +1673,10 @@ static int lm_score_impl(milan_ctx* c, const int64_t* seqs, int rows, int L,
                 "cannot use MI/rerank decoding without an LM");
   const size_t st_bytes =
       sizeof(float) * (size_t)b->lm[0].rows * d.lm_hidden_size * d.lm_layers;
-  MILAN_CHECK_HIP(hipMemsetAsync(b->lm[0].h, 0, st_bytes, s));
-  MILAN_CHECK_HIP(hipMemsetAsync(b->lm[0].c, 0, st_bytes, s));
+  MILAN_TRY(launch_zero_fill(b->lm[0].h, st_bytes, s));
+  MILAN_TRY(launch_zero_fill(b->lm[0].c, st_bytes, s));
   if (L < 2) {
-    MILAN_CHECK_HIP(hipMemsetAsync(total, 0, sizeof(float) * rows, s));
+    MILAN_TRY(launch_zero_fill(total, sizeof(float) * rows, s));
     return 0;
   }
   int cur = 0;
@@ -1686,9 +1686,7 @@ static int lm_score_impl(milan_ctx* c, const int64_t* seqs, int rows, int L,
   static const bool lse_on = !(getenv("MILAN_LM_LSE") && atoi(getenv("MILAN_LM_LSE")) == 0);
   const bool lse = lse_on && d.vocab_size % 4 == 0 && d.vocab_size >= 256;
   if (split)
-    MILAN_CHECK_HIP(hipMemsetAsync(
-        b->lm_gates, 0,
-        sizeof(float) * (size_t)rows * d.lm_hidden_size * d.lm_layers, s));
+    MILAN_TRY(launch_zero_fill(b->lm_gates, sizeof(float) * (size_t)rows * d.lm_hidden_size * d.lm_layers, s));
   for (int t = 0; t + 1 < L; ++t) {
     hipLaunchKernelGGL(gather_col_kernel, dim3(nblk(rows)), dim3(256), 0, s, seqs,
                        (long)rows, (long)L, t, b->tok);
@@ -1750,8 +1748,8 @@ int decoder_lm_logprobs(milan_ctx* c, const int64_t* seqs, int rows, int L,
                 "lm_logprobs: workspace too small (%zu needed)", ws.off);
   const size_t st_bytes =
       sizeof(float) * (size_t)b.lm[0].rows * d.lm_hidden_size * d.lm_layers;
-  MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].h, 0, st_bytes, s));
-  MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].c, 0, st_bytes, s));
+  MILAN_TRY(launch_zero_fill(b.lm[0].h, st_bytes, s));
+  MILAN_TRY(launch_zero_fill(b.lm[0].c, st_bytes, s));
   int cur = 0;
   for (int t = 0; t < L; ++t) {
     hipLaunchKernelGGL(gather_col_kernel, dim3(nblk(rows)), dim3(256), 0, s, seqs,
@@ -1818,8 +1816,8 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
   int lmcur = 0;
   if (mi) {
     const size_t st_bytes = sizeof(float) * (size_t)R * Hl * d.lm_layers;
-    MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].h, 0, st_bytes, s));
-    MILAN_CHECK_HIP(hipMemsetAsync(b.lm[0].c, 0, st_bytes, s));
+    MILAN_TRY(launch_zero_fill(b.lm[0].h, st_bytes, s));
+    MILAN_TRY(launch_zero_fill(b.lm[0].c, st_bytes, s));
   }
 
   if (greedy) {

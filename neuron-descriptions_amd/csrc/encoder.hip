@@ -1209,7 +1209,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
                        pl.bbox, pl.order, pl.bbox_c, pl.count);
     MILAN_CHECK_HIP(hipGetLastError());
     // rows of the images without work: exact zeros (the pooling writes the others)
-    MILAN_CHECK_HIP(hipMemsetAsync(features, 0, sizeof(float) * (size_t)n_all * c->d.feature_size, s));
+    MILAN_TRY(launch_zero_fill(features, sizeof(float) * (size_t)n_all * c->d.feature_size, s));
     order = pl.order;
     live = pl.count;
   }
@@ -1262,7 +1262,7 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     const float s0 = c->stdv[0], s1 = c->stdv[1], s2 = c->stdv[2];
     const void* mul = spatial ? masks : nullptr;  // spatial mode: x * mask
     const int mul_u8 = mask_dtype == MILAN_DTYPE_U8;
-    if (poison) MILAN_CHECK_HIP(hipMemsetAsync(poison, 0, sizeof(int) * (size_t)n, s));
+    if (poison) MILAN_TRY(launch_zero_fill(poison, sizeof(int) * (size_t)n, s));
     if (pair_stem && image_dtype == MILAN_DTYPE_U8)
       hipLaunchKernelGGL(preprocess_pairs_kernel<uint8_t>, dim3(blocks),
                          dim3(256), 0, s, (const uint8_t*)images, np, H, W, G,

@@ -2564,6 +2564,31 @@ static Profiler g_prof;
 
 // ---- status word of the calling context (common.h) ------------------------------------
 static thread_local unsigned* t_status_word = nullptr;
+__global__ void zero_fill_kernel(unsigned* __restrict__ p, size_t words) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const size_t quads = words >> 2;
+    for (size_t j = i; j < quads; j += stride) q[j] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t j = (quads << 2) + i; j < words; j += stride) p[j] = 0u;
+  } else {
+    for (; i < words; i += stride) p[i] = 0u;
+  }
+}
+
+int launch_zero_fill(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return 0;
+  MILAN_REQUIRE(p != nullptr && (bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0,
+                MILAN_ERR_ARG, "zero_fill: %zu bytes at %p", bytes, p);
+  const size_t words = bytes >> 2;
+  const size_t want = (words / 4 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<unsigned*>(p), words);
+  MILAN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 void set_status_word(unsigned* word) { t_status_word = word; }
 unsigned* status_word() { return t_status_word; }
 void profile_tag_kernel(int family) {

@@ -150,10 +150,11 @@ def test_encode_enqueues_without_synchronising(ctx):
         with torch.cuda.graph(graph, stream=side):
             out = ctx.encode(images, masks, check=False)
     torch.cuda.current_stream().wait_stream(side)
-    out.zero_()
-    graph.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(out, want)
+    for replay in range(3):   # (a memset NODE went wrong from the second replay on: launch_zero_fill)
+        out.fill_(float(replay + 5))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), replay
     assert (out[[2, 5]] == 0).all() and ctx.status() == 0
     # a different set of empty masks through the SAME graph: the count is data, not a launch
     # parameter

@@ -31,6 +31,7 @@ def main():
                                     group_size=16, check=False)
         want = call()
         torch.cuda.synchronize()
+        st = [ctx.status()]
         reps = 5
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -42,11 +43,16 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             call()
+            torch.cuda.synchronize()
+            st.append(ctx.status())
             with torch.cuda.graph(graph, stream=side):
                 out = call()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        st.append(ctx.status())
         graph.replay()
         torch.cuda.synchronize()
+        st.append(ctx.status())
         same = all(torch.equal(out[k], want[k]) for k in ('tokens', 'scores'))
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -54,7 +60,8 @@ def main():
         torch.cuda.synchronize()
         replay = (time.perf_counter() - t0) / reps
         print(f'{n:4d} neurons: eager {1e3 * eager:8.2f} ms   graph replay {1e3 * replay:8.2f} ms   '
-              f'({eager / replay:.3f} x)   status {ctx.status()}   identical {same}', flush=True)
+              f'({eager / replay:.3f} x)   status after eager / side-stream eager / capture / first replay / timed replays '
+              f'{st + [ctx.status()]}   identical {same}', flush=True)
     ctx.close()
 
 
