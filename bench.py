@@ -72,8 +72,33 @@ def lm_gflop(beam: int, rerank: bool, e: int = 128, h: int = 512,
     return 2 * beam * 16 * ((e + h) * 4 * h + 2 * h * 4 * h + h * v) / 1e9
 
 
-def algorithmic_gflop(beam: int, rerank: bool) -> float:
-    return GFLOP_ENCODER + decoder_gflop(beam) + lm_gflop(beam, rerank)
+def algorithmic_gflop(beam: int, rerank: bool, lm_rows=None) -> float:
+    """SURVEY.md 8(d) per neuron-description.  `lm_rows` = (LSTM, vocabulary) fractions of the
+    B x beam rows the rerank pass really multiplies (round 6: beams that share a prefix share
+    their LM state -- the duplicate rows are redundant work like the per-row key projection the
+    survey's hoisted form already excludes); None = every row, the survey's 9.55 GFLOP."""
+    if lm_rows is None or not rerank:
+        return GFLOP_ENCODER + decoder_gflop(beam) + lm_gflop(beam, rerank)
+    e, h, v = 128, 512, 5004
+    lm = 2 * beam * 16 * (((e + h) * 4 * h + 2 * h * 4 * h) * lm_rows[0] + h * v * lm_rows[1]) / 1e9
+    return GFLOP_ENCODER + decoder_gflop(beam) + lm
+
+
+def lm_row_fractions(beam_tokens: torch.Tensor):
+    """Fractions of the rerank pass's rows that are distinct work (accounting only, outside any
+    timed region): at LM step t a row's LSTM state depends on its first t tokens only, its
+    vocabulary product on the first t + 1 -- count the distinct prefixes per neuron."""
+    n, b, t = beam_tokens.shape
+    key = torch.zeros(n, b, dtype=torch.int64, device=beam_tokens.device)
+    uniq = []
+    for i in range(t):
+        key = key * 1000003 + beam_tokens[:, :, i] + 1
+        srt = key.sort(dim=1).values
+        uniq.append(1 + (srt[:, 1:] != srt[:, :-1]).sum(dim=1))   # (n,)
+    u = torch.stack(uniq, dim=1).double()                          # (n, t): distinct prefixes of length i + 1
+    lstm = (1 + u[:, :t - 1].sum(dim=1)).mean() / (b * t)
+    vocab = u.sum(dim=1).mean() / (b * t)
+    return float(lstm), float(vocab)
 
 
 def pooled_bytes_per_image(masks: torch.Tensor, width: int = 64) -> float:
@@ -658,6 +683,7 @@ def main():
     # split-f16 fails loudly: bit 0 = a value hit the +-65504 clamp in ANY timed step
     status_flags = ctx.status(clear=True)
     gemm_ms = gemm_flops = gemm_launches = stages = kernels = None
+    lm_rows = None
     if not args.no_profile:
         gemm_ms, gemm_flops, gemm_launches = hip.profile_read()
         stages = hip.profile_read_stages()
@@ -678,6 +704,23 @@ def main():
             if fam in kernels and fam not in ('pp32_256',):   # (pp32_256 also holds the decoder / LM products)
                 kernels[fam]['flops'] *= live_frac
                 kernels[fam]['bytes'] *= live_frac
+        # Round 6: the rerank pass multiplies only the rows that are distinct work (beams that
+        # share a prefix share their LM state; the class counts stay on the device), while the
+        # library prices its launches at the B x beam rows they are SIZED for.  The fractions
+        # follow from the beams themselves: take the over-count out of the family that holds
+        # the LM's products (N = 2048 and N = 5004: the 256-column ping-pong tile).
+        if rerank and os.environ.get('MILAN_LM_DEDUP', '1') != '0' and args.precision != 'f32' \
+                and outs and outs[0].get('beam_tokens') is not None:
+            fr = [lm_row_fractions(o['beam_tokens']) for o in outs]
+            w = [float(sz) for sz in sizes[:len(fr)]]
+            lm_rows = (sum(f[0] * x for f, x in zip(fr, w)) / sum(w),
+                       sum(f[1] * x for f, x in zip(fr, w)) / sum(w))
+            e_, h_, v_ = 128, 512, nv + 4
+            row_steps = float(my_neurons) * beam * args.length
+            over = 2.0 * row_steps * (((e_ + h_) * 4 * h_ + 2 * h_ * 4 * h_) * (1 - lm_rows[0]) +
+                                      h_ * v_ * (1 - lm_rows[1]))
+            if 'pp32_256' in kernels and kernels['pp32_256']['flops'] > over:
+                kernels['pp32_256']['flops'] -= over
         # by rocprofv3 symbol (top_kernels below) ...
         kernels_by_symbol = {k: dict(v) for k, v in kernels.items()}
         # ... and by tile function: the ping-pong tile and its tap-inner form are ONE family
@@ -914,7 +957,7 @@ def main():
                 (f"; not measured live: {live_reason}" if live_reason else ''))
             break
     if gemm_ms:
-        g_alg = algorithmic_gflop(beam, rerank)
+        g_alg = algorithmic_gflop(beam, rerank, lm_rows)
         per_launch_flop = g_alg * 1e9 * my_neurons / gemm_launches
         avg_ms = gemm_ms / gemm_launches
         achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
@@ -927,8 +970,9 @@ def main():
             stages['dec_search']['gemm_flops'] = (
                 decoder_gflop(beam) * 1e9 * my_neurons -
                 stages['dec_init']['gemm_flops'])
-            stages['dec_lm']['gemm_flops'] = lm_gflop(beam, rerank) * 1e9 * \
-                my_neurons
+            stages['dec_lm']['gemm_flops'] = (
+                algorithmic_gflop(beam, rerank, lm_rows) - GFLOP_ENCODER -
+                decoder_gflop(beam)) * 1e9 * my_neurons
         pool_bytes = pooled_bytes_per_image(masks[:args.chunk])
         # the DOMINANT kernel priced on its own launches (milan_profile_read_kernels):
         # algorithmic FLOPs of its launches / their summed HIP-event time
@@ -976,6 +1020,11 @@ def main():
                 for k, v in sorted(kernels_by_symbol.items(), key=lambda kv: -kv[1]['ms'])[:3]
                 if v['ms'] > 0],
             'live_image_fraction': live_frac,
+            # fractions of the B x beam rows the rerank pass multiplies (LSTM, vocabulary): beams
+            # that share a prefix share their LM state.  `algorithmic_gflop_per_neuron` counts
+            # the LM at these fractions; the survey's every-row figure is 263.49
+            'lm_rows_multiplied_fraction': list(lm_rows) if lm_rows else None,
+            'survey_gflop_per_neuron': algorithmic_gflop(beam, rerank),
             'by_kernel': {k: {'ms_per_step': v['ms'] / n_steps,
                               'launches_per_step': v['launches'] / n_steps,
                               'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
