@@ -1326,10 +1326,13 @@ struct DecBuf {
   float* last_lp[2]; int *new_tok, *new_bp, *hist_tok, *hist_bp;
   int64_t *tok, *seqs;
   float *lm_alive, *lm_total;
+  float* lm_dedup; size_t lm_dedup_floats;   // scratch of the prefix-class rerank pass (lm_score_dedup)
   int32_t* len1;
   float* scratch;
   size_t scratch_floats;
 };
+
+static size_t lm_dedup_floats(const milan_dims& d, size_t R, int L, int G);
 
 static void dec_plan(const milan_ctx* c, int n, int k, int beam, int T, bool lm,
                      Arena& a, DecBuf* b) {
@@ -1361,6 +1364,7 @@ static void dec_plan(const milan_ctx* c, int n, int k, int beam, int T, bool lm,
     b->scratch = a.get<float>(b->scratch_floats);
   }
   b->lm_logits = nullptr;
+  b->lm_dedup = nullptr; b->lm_dedup_floats = 0;
   if (lm) {
     const int Hl = d.lm_hidden_size, El = d.lm_embedding_size;
     b->lm_logits = a.get<float>(R * V);
@@ -1373,6 +1377,9 @@ static void dec_plan(const milan_ctx* c, int n, int k, int beam, int T, bool lm,
     }
     b->lm_alive = a.get<float>(R);
     b->lm_total = a.get<float>(R);
+    // the rerank pass's prefix classes + gathered states (~2.6 k floats per row at Hl = 512)
+    b->lm_dedup_floats = beam > 1 ? lm_dedup_floats(d, R, T + 1, n) : 0;
+    b->lm_dedup = b->lm_dedup_floats ? a.get<float>(b->lm_dedup_floats) : nullptr;
   }
 }
 
@@ -1799,7 +1806,7 @@ struct LmDedup {
   int64_t *tok_c, *tgt_c;          // [R]
 };
 
-// floats of scratch the dedup pass needs (carved from the search stage's logits buffer)
+// floats of scratch the dedup pass needs (dec_plan)
 static size_t lm_dedup_floats(const milan_dims& d, size_t R, int L, int G) {
   const size_t maps = 5 * (size_t)(L + 1) * R + 2 * (size_t)(L + 1) * G + (size_t)(L + 1) + 64;
   const size_t state = (2 * (size_t)d.lm_layers + 1) * R * d.lm_hidden_size;
@@ -2165,10 +2172,8 @@ int decoder_decode(milan_ctx* c, const float* features, int n, int k,
     hipLaunchKernelGGL(len_plus_one_kernel, dim3(nblk(groups)), dim3(256), 0, s,
                        lens, groups, b.len1);
     b.lm[0].rows = b.lm[1].rows = R;
-    // (the search stage's logits buffer is dead by now: scratch of the prefix-class pass)
     MILAN_TRY(lm_score_impl(c, b.seqs, R, length + 1, b.len1, beam * group_size,
-                            b.lm_total, &b, s, beam, b.logits,
-                            (size_t)R * d.vocab_size));
+                            b.lm_total, &b, s, beam, b.lm_dedup, b.lm_dedup_floats));
     lm_scores = b.lm_total;
   }
   hipLaunchKernelGGL(rerank_select_kernel, dim3(nblk(n)), dim3(256), 0, s,
