@@ -84,6 +84,19 @@ def algorithmic_gflop(beam: int, rerank: bool, lm_rows=None) -> float:
     return GFLOP_ENCODER + decoder_gflop(beam) + lm
 
 
+def tail_row_fractions(masks: torch.Tensor):
+    """Fractions of the last stage's 7 x 7 pixels the mask-aware tail (round 6) computes
+    (accounting only): f0 = pixels with a non-zero level-4 mask weight (the central 2 x 2 of
+    their 32 x 32 block holds a set mask pixel), f1 / f2 = their 3 x 3 neighbourhoods once /
+    twice.  masks: (..., 224, 224) uint8."""
+    m = (masks.reshape(-1, masks.shape[-2], masks.shape[-1]) != 0).float()
+    c = (m[:, 15::32, 15::32] + m[:, 16::32, 15::32] + m[:, 15::32, 16::32] + m[:, 16::32, 16::32]) > 0
+    f0 = c.float().unsqueeze(1)
+    f1 = torch.nn.functional.max_pool2d(f0, 3, 1, 1)
+    f2 = torch.nn.functional.max_pool2d(f1, 3, 1, 1)
+    return float(f0.mean()), float(f1.mean()), float(f2.mean())
+
+
 def lm_row_fractions(beam_tokens: torch.Tensor):
     """Fractions of the rerank pass's rows that are distinct work (accounting only, outside any
     timed region): at LM step t a row's LSTM state depends on its first t tokens only, its
@@ -684,6 +697,7 @@ def main():
     status_flags = ctx.status(clear=True)
     gemm_ms = gemm_flops = gemm_launches = stages = kernels = None
     lm_rows = None
+    tail_rows, tail_over_per_image = None, 0.0
     if not args.no_profile:
         gemm_ms, gemm_flops, gemm_launches = hip.profile_read()
         stages = hip.profile_read_stages()
@@ -721,6 +735,26 @@ def main():
                                       h_ * v_ * (1 - lm_rows[1]))
             if 'pp32_256' in kernels and kernels['pp32_256']['flops'] > over:
                 kernels['pp32_256']['flops'] -= over
+        # ... and the mask-aware tail: the last two bottlenecks run at the pixels the level-4
+        # pooling (and their 3x3 neighbourhoods) read; their launches are sized for all 49.
+        tail_rows = None
+        tail_over_per_image = 0.0
+        if args.precision != 'f32' and (int(os.environ.get('MILAN_CHAIN', '127')) & 64):
+            acc = [0.0, 0.0, 0.0]
+            for i in range(n_steps):
+                f = tail_row_fractions(step_data[i][1][:sizes[i]])
+                for q in range(3):
+                    acc[q] += f[q] * sizes[i]
+            tail_rows = tuple(a / max(1, sum(sizes[:n_steps])) for a in acc)
+            c1 = 49 * 2048 * 512
+            c23 = 49 * (9 * 512 * 512 + 512 * 2048)
+            tail_over_per_image = 2.0 * (c1 * (1 - tail_rows[1]) + c23 * (1 - tail_rows[0]) +
+                                         c1 * (1 - tail_rows[2]) + c23 * (1 - tail_rows[1]))
+            over = tail_over_per_image * 15 * my_neurons
+            if 'pp32_256' in kernels and kernels['pp32_256']['flops'] > over:
+                kernels['pp32_256']['flops'] -= over
+            if stages is not None and stages['enc_layer4']['gemm_flops'] > over:
+                stages['enc_layer4']['gemm_flops'] -= over
         # by rocprofv3 symbol (top_kernels below) ...
         kernels_by_symbol = {k: dict(v) for k, v in kernels.items()}
         # ... and by tile function: the ping-pong tile and its tap-inner form are ONE family
@@ -957,7 +991,8 @@ def main():
                 (f"; not measured live: {live_reason}" if live_reason else ''))
             break
     if gemm_ms:
-        g_alg = algorithmic_gflop(beam, rerank, lm_rows)
+        # (the tail's skipped rows are not credited as work either)
+        g_alg = algorithmic_gflop(beam, rerank, lm_rows) - tail_over_per_image * 15 / 1e9
         per_launch_flop = g_alg * 1e9 * my_neurons / gemm_launches
         avg_ms = gemm_ms / gemm_launches
         achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
@@ -1024,6 +1059,9 @@ def main():
             # that share a prefix share their LM state.  `algorithmic_gflop_per_neuron` counts
             # the LM at these fractions; the survey's every-row figure is 263.49
             'lm_rows_multiplied_fraction': list(lm_rows) if lm_rows else None,
+            # fractions of the last stage's pixels the last two bottlenecks are computed at: the
+            # pixels the level-4 pooling reads, their 3x3 neighbourhoods once / twice
+            'tail_rows_computed_fraction': list(tail_rows) if tail_rows else None,
             'survey_gflop_per_neuron': algorithmic_gflop(beam, rerank),
             'by_kernel': {k: {'ms_per_step': v['ms'] / n_steps,
                               'launches_per_step': v['launches'] / n_steps,

@@ -269,7 +269,9 @@ enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound,
        MILAN_FUSE_STEM = 4,
        MILAN_FUSE_CONV3 = 8,       /* layer1's 3x3 convs: weights in registers (csrc/conv3.hip) */
        MILAN_FUSE_SKIP_EMPTY = 16,
-       MILAN_FUSE_BNECK = 32 };    /* layer1: the 3x3 conv in front of the chain launch (round 6) */
+       MILAN_FUSE_BNECK = 32,      /* layer1: the 3x3 conv in front of the chain launch (round 6) */
+       MILAN_FUSE_SPARSE_TAIL = 64 };  /* the last two bottlenecks only at the pixels the level-4
+                                          pooling (and their 3x3 neighbourhoods) read (round 6) */
 int milan_set_fusion(milan_ctx* ctx, int flags);
 int milan_set_precision(milan_ctx* ctx, int precision);
 int milan_get_precision(const milan_ctx* ctx);

@@ -494,7 +494,7 @@ int milan_conv2d_nhwc(const float* x, int n, int h, int w, int cin,
 int milan_set_fusion(milan_ctx* c, int flags) {
   MILAN_REQUIRE(c, MILAN_ERR_ARG, "null ctx");
   MILAN_REQUIRE((flags & ~(MILAN_FUSE_CHAIN | MILAN_FUSE_CHAIN_WIDE | MILAN_FUSE_STEM | MILAN_FUSE_CONV3 |
-                           MILAN_FUSE_SKIP_EMPTY | MILAN_FUSE_BNECK)) == 0, MILAN_ERR_ARG,
+                           MILAN_FUSE_SKIP_EMPTY | MILAN_FUSE_BNECK | MILAN_FUSE_SPARSE_TAIL)) == 0, MILAN_ERR_ARG,
                 "unknown fusion flags %d", flags);
   c->fusion = flags;
   return 0;

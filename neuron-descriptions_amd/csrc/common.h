@@ -478,7 +478,7 @@ struct milan_ctx {
                       // decoder, LM and the front of the trunk stay split)
   int trunk_f16 = 0;  // MILAN_PRECISION_F16: layer3 / layer4 of a bottleneck trunk on plain f16
   int fusion = MILAN_FUSE_CHAIN | MILAN_FUSE_CHAIN_WIDE | MILAN_FUSE_STEM | MILAN_FUSE_CONV3 |
-               MILAN_FUSE_SKIP_EMPTY | MILAN_FUSE_BNECK;  // milan_set_fusion
+               MILAN_FUSE_SKIP_EMPTY | MILAN_FUSE_BNECK | MILAN_FUSE_SPARSE_TAIL;  // milan_set_fusion
   // hipGraph cache of whole decode passes (milan_set_graph_capture)
   int graph_capture = 0;
   struct GraphEntry { std::vector<char> key; hipGraphExec_t exec = nullptr; int seen = 0; };

@@ -953,6 +953,139 @@ __global__ void act_absmax_kernel(const float* __restrict__ x, long n,
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+
+// ---------------------------------------------------------------------------
+// Mask-aware tail of the last stage (round 6, MILAN_FUSE_SPARSE_TAIL)
+// ---------------------------------------------------------------------------
+// The last stage's output is read by NOTHING but the level-4 pooling, and that reads only the
+// pixels under the (bilinearly shrunk) mask: on the benchmark's masks 5.3 of 49 pixels per
+// image.  Working backwards through the last two bottlenecks (neither has a downsample
+// branch): the last block's c3 / c2 are needed at those pixels S2, its c1 -- and the block
+// before it, as input and residual -- at their 3x3 neighbourhoods S1 = dilate(S2) (33 %), that
+// block's c1 at S0 = dilate(S1) (56 %).  The reference computes all 49 and multiplies most by
+// zero (src/milan/encoders.py:310-317); here the row sets are built on the device from the
+// pooling's own pixel lists, the 1x1 convs run over gathered rows, the 3x3 over an explicit
+// im2col of the needed rows in the (slice, tap, channel) order of the tap-inner kernel -- the
+// same products in the same order, so the pooled features are bitwise those of the dense pass
+// (tests/test_gpu_sparse_tail.py) -- and the row counts stay on the device (GemmArgs::m_live).
+constexpr int kTailMaxP = 1024;   // pixels of the last stage per image (7 x 7 = 49 at 224 x 224)
+
+// sets k = 0 (listed pixels), 1 (dilated once), 2 (dilated twice) of batch slot j, ascending
+__global__ __launch_bounds__(64) void tail_sets_kernel(
+    const int* __restrict__ list_idx, const int* __restrict__ list_n, Levels lv,
+    const int* __restrict__ order, const int* __restrict__ live, int n,
+    int* __restrict__ loc, int* __restrict__ cnt) {
+  __shared__ unsigned char s[3][kTailMaxP];
+  const int j = blockIdx.x, lane = threadIdx.x;
+  const int h = lv.h[4], w = lv.w[4], P = h * w;
+  if (live != nullptr && j >= *live) {
+    if (lane < 3) cnt[lane * n + j] = 0;
+    return;
+  }
+  const int img = order ? order[j] : j;
+  for (int p = lane; p < P; p += 64) s[0][p] = 0;
+  __syncthreads();
+  const long base = (long)img * lv.per_image + lv.off[4];
+  const int c = list_n[img * 5 + 4];
+  for (int i = lane; i < c; i += 64) s[0][list_idx[base + i]] = 1;
+  __syncthreads();
+  for (int k = 1; k < 3; ++k) {
+    for (int p = lane; p < P; p += 64) {
+      const int y = p / w, x = p - y * w;
+      unsigned char v = 0;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy >= 0 && yy < h && xx >= 0 && xx < w) v |= s[k - 1][yy * w + xx];
+        }
+      s[k][p] = v;
+    }
+    __syncthreads();
+  }
+  for (int k = 0; k < 3; ++k) {
+    int count = 0;
+    int* out = loc + ((long)k * n + j) * P;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+      const int p = p0 + lane;
+      const bool nz = p < P && s[k][p];
+      const unsigned long long m = __ballot(nz);
+      if (nz) out[count + __popcll(m & ((1ull << lane) - 1ull))] = p;
+      count += __popcll(m);
+    }
+    if (lane == 0) cnt[k * n + j] = count;
+  }
+}
+
+// off[k][j] = rows of set k in the slots before j; U[k] = their total
+__global__ __launch_bounds__(256) void tail_scan_kernel(const int* __restrict__ cnt, int n,
+                                                        int* __restrict__ off, int* __restrict__ U) {
+  __shared__ int tmp[256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  int base = 0;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + tid;
+    const int v = j < n ? cnt[(long)k * n + j] : 0;
+    tmp[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int add = tid >= o ? tmp[tid - o] : 0;
+      __syncthreads();
+      tmp[tid] += add;
+      __syncthreads();
+    }
+    if (j < n) off[(long)k * n + j] = base + tmp[tid] - v;
+    base += tmp[255];
+    __syncthreads();
+  }
+  if (tid == 0) U[k] = base;
+}
+
+// rows[k][off[k][j] + i] = j * P + loc[k][j][i]  (row of the dense (slot, pixel) tensors)
+__global__ void tail_fill_kernel(const int* __restrict__ loc, const int* __restrict__ cnt,
+                                 const int* __restrict__ off, int n, int P, int* __restrict__ rows) {
+  const int j = blockIdx.x, k = blockIdx.y;
+  const int c = cnt[k * n + j], o = off[k * n + j];
+  for (int i = threadIdx.x; i < c; i += blockDim.x)
+    rows[(long)k * n * P + o + i] = j * P + loc[((long)k * n + j) * P + i];
+}
+
+// dst[u][:] = src[idx[u]][:] / dst[idx[u]][:] = src[u][:]  (rows of w4 x 16 bytes), u < *live
+template <bool SCATTER>
+__global__ void tail_rows_kernel(const float4* __restrict__ src, const int* __restrict__ idx,
+                                 const int* __restrict__ live, int w4, float4* __restrict__ dst) {
+  const long total = (long)*live * w4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long u = i / w4;
+    const int q = (int)(i - u * w4);
+    if (SCATTER) dst[(long)idx[u] * w4 + q] = src[i];
+    else dst[i] = src[(long)idx[u] * w4 + q];
+  }
+}
+
+// explicit im2col of a 3x3 / 1 / 1 conv for the rows in `rows`: column order (32-channel slice,
+// tap, channel) = the k order of the tap-inner ping-pong kernel and of ConvW::wst; pixels
+// outside the image contribute zeros.  t1: dense [slots * P][C] split format, C % 32 == 0.
+__global__ void tail_im2col_kernel(const float4* __restrict__ t1, const int* __restrict__ rows,
+                                   const int* __restrict__ live, int h, int w, int C,
+                                   float4* __restrict__ acol) {
+  const int per = 9 * C / 4, P = h * w, c4 = C / 4;
+  const long total = (long)*live * per;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long u = i / per;
+    const int q = (int)(i - u * per);
+    const int sl = q / 72, r = q - sl * 72, tap = r >> 3, f = r & 7;
+    const int row = rows[u];
+    const int j = row / P, p = row - j * P;
+    const int y = p / w + tap / 3 - 1, x = p % w + tap % 3 - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y >= 0 && y < h && x >= 0 && x < w)
+      v = t1[((long)j * P + y * w + x) * c4 + sl * 8 + f];
+    acol[i] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // driver
 // ---------------------------------------------------------------------------
@@ -966,6 +1099,9 @@ struct EncPlan {
   int* bbox;  // [n][4]: level-0 bounding box of the listed pixels
   int* poison;  // [n]: 1 = the image holds a non-finite pixel (float inputs only)
   int *order, *bbox_c, *count;  // images with a non-empty mask (compact_images_kernel)
+  // mask-aware tail of the last stage: per-slot pixel sets [3][n][P4], their counts / offsets
+  // [3][n], the global row lists [3][n * P4] and row counts [3] (device)
+  int *tail_loc, *tail_cnt, *tail_off, *tail_rows, *tail_U;
 };
 
 static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
@@ -1014,6 +1150,14 @@ static int plan(const milan_ctx* c, int n, int H, int W, Arena& a, EncPlan* pl) 
   pl->order = a.get<int>((size_t)n);
   pl->bbox_c = a.get<int>((size_t)n * 4);
   pl->count = a.get<int>(4);
+  {
+    const size_t P4 = (size_t)lv.h[4] * lv.w[4];
+    pl->tail_loc = a.get<int>(3 * (size_t)n * P4);
+    pl->tail_rows = a.get<int>(3 * (size_t)n * P4);
+    pl->tail_cnt = a.get<int>(3 * (size_t)n);
+    pl->tail_off = a.get<int>(3 * (size_t)n);
+    pl->tail_U = a.get<int>(4);
+  }
   return 0;
 }
 
@@ -1390,6 +1534,79 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
     if (c->calib && !split) MILAN_TRY(track(g.C, (long)g.M * g.N));
     return 0;
   };
+  // 3b. mask-aware tail of the last stage (MILAN_FUSE_SPARSE_TAIL): the row sets the last two
+  // bottlenecks are needed at, from the level-4 pixel lists (kernels above)
+  const int P4 = pl.lv.h[4] * pl.lv.w[4];
+  bool tail = split && !fast && !spatial && masks != nullptr && c->calib == nullptr &&
+              (c->fusion & MILAN_FUSE_SPARSE_TAIL) && c->d.trunk_kind == MILAN_TRUNK_BOTTLENECK &&
+              c->blocks[3].size() >= 2 && P4 >= 1 && P4 <= kTailMaxP;
+  if (tail) {
+    const Bottleneck& lb = c->blocks[3].back();
+    // scratch of a sparse block = the raw conv1 tensor (dead after the level-0 pooling)
+    const size_t need = (size_t)P4 * ((size_t)2 * lb.c1.cin + lb.c3.cout + (size_t)11 * lb.c1.cout);
+    tail = need <= (size_t)pl.h1 * pl.w1 * wd;
+  }
+  if (tail) {
+    hipLaunchKernelGGL(tail_sets_kernel, dim3(n), dim3(64), 0, s, pl.list_idx, pl.list_n, pl.lv,
+                       order, live, n, pl.tail_loc, pl.tail_cnt);
+    hipLaunchKernelGGL(tail_scan_kernel, dim3(3), dim3(256), 0, s, pl.tail_cnt, n, pl.tail_off,
+                       pl.tail_U);
+    hipLaunchKernelGGL(tail_fill_kernel, dim3(n, 3), dim3(64), 0, s, pl.tail_loc, pl.tail_cnt,
+                       pl.tail_off, n, P4, pl.tail_rows);
+    MILAN_CHECK_HIP(hipGetLastError());
+  }
+  auto tail_block_ok = [&](const Bottleneck& b) {
+    return !b.basic && !b.has_down && b.c1.ws && b.c2.ws && b.c2.wst && b.c3.ws && b.c1.bias_s &&
+           b.c2.bias_s && b.c3.bias_s && b.c1.kh == 1 && b.c1.kw == 1 && b.c1.stride == 1 &&
+           b.c2.kh == 3 && b.c2.kw == 3 && b.c2.stride == 1 && b.c2.pad == 1 && b.c3.kh == 1 &&
+           b.c3.kw == 1 && b.c3.stride == 1 && b.c1.K == b.c1.Kp && b.c2.K == b.c2.Kp &&
+           b.c3.K == b.c3.Kp && b.c1.cout % 32 == 0 && b.c2.cin == b.c1.cout &&
+           b.c2.cout == b.c1.cout && b.c3.cin == b.c1.cout && b.c3.cout == b.c1.cin &&
+           b.c1.cin % 4 == 0;
+  };
+  // one bottleneck on row sets: c1 at set kM (the 3x3 neighbourhoods of set kO), c2 / c3 at set kO;
+  // X is dense [n * P4][4P] (valid at least on set kM), Y gets the rows of set kO
+  auto tail_block = [&](const Bottleneck& b, const float* X, float* Y, float* T1, int hh,
+                        int ww, int kM, int kO) -> int {
+    const long rows_all = (long)n * P4;
+    const int Cin = b.c1.cin, P = b.c1.cout, Cout = b.c3.cout;
+    float* xg = pl.raw;
+    float* t1c = xg + rows_all * Cin;
+    float* acol = t1c + rows_all * P;
+    float* t2c = acol + rows_all * 9 * P;
+    float* rg = t2c + rows_all * P;
+    float* yc = rg + rows_all * Cin;
+    const int* rowsM = pl.tail_rows + (long)kM * n * P4;
+    const int* rowsO = pl.tail_rows + (long)kO * n * P4;
+    const int* UM = pl.tail_U + kM;
+    const int* UO = pl.tail_U + kO;
+    auto blocks_for = [](long items) { return (int)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192); };
+    auto lin = [&](const float* A, int K, const ConvW& cw, const float* W, float* C, int N, int epi,
+                   const float* aux, const int* U) -> int {
+      GemmArgs g = linear_args(A, K, W, cw.bias_s, C, N, (int)rows_all, N, K, epi, c->zero, aux, N);
+      g.a_split = 1; g.out_split = 1; g.aux_split = aux != nullptr;
+      g.acc_scale = cw.ws_inv;
+      g.flop_k = cw.kh * cw.kw * cw.cin_real;
+      g.m_live = U; g.m_live_mul = 1;
+      return launch_gemm(g, s);
+    };
+    hipLaunchKernelGGL(tail_rows_kernel<false>, dim3(blocks_for(rows_all * (Cin / 4))), dim3(256), 0, s,
+                       (const float4*)X, rowsM, UM, Cin / 4, (float4*)xg);
+    MILAN_TRY(lin(xg, Cin, b.c1, b.c1.ws, t1c, P, EPI_BIAS_RELU, nullptr, UM));
+    hipLaunchKernelGGL(tail_rows_kernel<true>, dim3(blocks_for(rows_all * (P / 4))), dim3(256), 0, s,
+                       (const float4*)t1c, rowsM, UM, P / 4, (float4*)T1);
+    hipLaunchKernelGGL(tail_im2col_kernel, dim3(blocks_for(rows_all * (9 * P / 4))), dim3(256), 0, s,
+                       (const float4*)T1, rowsO, UO, hh, ww, P, (float4*)acol);
+    MILAN_TRY(lin(acol, 9 * P, b.c2, b.c2.wst, t2c, P, EPI_BIAS_RELU, nullptr, UO));
+    hipLaunchKernelGGL(tail_rows_kernel<false>, dim3(blocks_for(rows_all * (Cin / 4))), dim3(256), 0, s,
+                       (const float4*)X, rowsO, UO, Cin / 4, (float4*)rg);
+    MILAN_TRY(lin(t2c, P, b.c3, b.c3.ws, yc, Cout, EPI_BIAS_RES_RELU, rg, UO));
+    hipLaunchKernelGGL(tail_rows_kernel<true>, dim3(blocks_for(rows_all * (Cout / 4))), dim3(256), 0, s,
+                       (const float4*)yc, rowsO, UO, Cout / 4, (float4*)Y);
+    MILAN_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+
   // 4. bottleneck stages; tap after each stage
   float *x = pl.x0, *y = pl.x1;
   int h = pl.hp, w = pl.wp, col = wd;
@@ -1440,6 +1657,16 @@ static int encoder_run_batch(milan_ctx* c, const void* images, int image_dtype,
         }
         float* tmp = x; x = y; y = tmp;
         h = h3; w = w3;
+        continue;
+      }
+      if (tail && li == 3 && bi >= 1 && bi + 2 >= blocks.size() && tail_block_ok(b) &&
+          (bi + 1 == blocks.size() || tail_block_ok(blocks.back())) &&
+          h == pl.lv.h[4] && w == pl.lv.w[4]) {
+        // the last block is needed at the listed pixels (set 0) and its c1 at set 1; the block
+        // before it at set 1 and its c1 at set 2
+        const int kO = bi + 1 == blocks.size() ? 0 : 1;
+        MILAN_TRY(tail_block(b, x, y, t1buf, h, w, kO + 1, kO));
+        float* tmp = x; x = y; y = tmp;
         continue;
       }
       if (b.basic) {

@@ -24,7 +24,7 @@ GREEDY, FORCED, BEAM, RERANK = 0, 1, 2, 3  # MILAN_GREEDY / _FORCED / _BEAM / _R
 PRECISION_F32, PRECISION_SPLIT_F16, PRECISION_F16 = 0, 1, 2
 # 'f16' = the fast mode: narrower than the reference's fp32 (include/milan_hip.h), never a default
 PRECISIONS = {'f32': PRECISION_F32, 'split_f16': PRECISION_SPLIT_F16, 'f16': PRECISION_F16}
-FUSE_CHAIN, FUSE_CHAIN_WIDE, FUSE_STEM, FUSE_CONV3, FUSE_SKIP_EMPTY, FUSE_BNECK = 1, 2, 4, 8, 16, 32  # milan_set_fusion flags (include/milan_hip.h)
+FUSE_CHAIN, FUSE_CHAIN_WIDE, FUSE_STEM, FUSE_CONV3, FUSE_SKIP_EMPTY, FUSE_BNECK, FUSE_SPARSE_TAIL = 1, 2, 4, 8, 16, 32, 64  # milan_set_fusion flags (include/milan_hip.h)
 SKETCH_COMPACT, SKETCH_INSERT, SKETCH_MOVE, SKETCH_HALVE = 0, 1, 2, 3
 # milan_status bits (include/milan_hip.h)
 STATUS_SATURATED, STATUS_NONFINITE_INPUT = 1, 2
@@ -342,7 +342,7 @@ class Context:
             bits = int(os.environ['MILAN_CHAIN'])
             self.set_fusion(chain=bool(bits & 1), wide=bool(bits & 2), stem=bool(bits & 4),
                             conv3=bool(bits & 8), skip_empty=bool(bits & 16),
-                            bneck=bool(bits & 32))
+                            bneck=bool(bits & 32), sparse_tail=bool(bits & 64))
         default = os.environ.get('MILAN_PRECISION')
         if default == 'auto':
             self.set_precision('split_f16')
@@ -388,18 +388,21 @@ class Context:
 
     def set_fusion(self, chain: bool = True, wide: Optional[bool] = None,
                    stem: bool = True, conv3: bool = True, skip_empty: bool = True,
-                   bneck: bool = True) -> None:
+                   bneck: bool = True, sparse_tail: bool = True) -> None:
         """Cross-layer fusions of the trunk (bitwise-neutral scheduling knob):
         `chain` the expand -> reduce launches of layer1 / layer2, `wide` those of
         layer3 (default: as `chain`), `stem` conv1 + bn1 + ReLU + maxpool as one launch, `conv3` the
         register-resident-weight kernel for layer1's 3x3 convolutions, `skip_empty` exemplars
         with an all-zero mask (exact-zero features by the reference's rule) stay out of the trunk,
-        `bneck` (round 6) layer1's 3x3 conv runs in front of its chain launch (needs `chain`)."""
+        `bneck` (round 6) layer1's 3x3 conv runs in front of its chain launch (needs `chain`),
+        `sparse_tail` (round 6) the last two bottlenecks run only at the pixels the level-4 pooling
+        -- and their 3x3 neighbourhoods -- read."""
         wide = chain if wide is None else wide
         _check(self.lib.milan_set_fusion(
             self._h, (FUSE_CHAIN if chain else 0) | (FUSE_CHAIN_WIDE if wide else 0) |
             (FUSE_STEM if stem else 0) | (FUSE_CONV3 if conv3 else 0) |
-            (FUSE_SKIP_EMPTY if skip_empty else 0) | (FUSE_BNECK if bneck else 0)))
+            (FUSE_SKIP_EMPTY if skip_empty else 0) | (FUSE_BNECK if bneck else 0) |
+            (FUSE_SPARSE_TAIL if sparse_tail else 0)))
 
     @property
     def precision(self) -> str:

@@ -119,5 +119,5 @@ def test_chain_encoder_matches_oracle_at_full_width(dev):
 def test_fusion_flags_are_validated(dev):
     ctx, _ = _ctx('resnet50', 16, dev)
     with pytest.raises((ValueError, RuntimeError)):
-        hip._check(ctx.lib.milan_set_fusion(ctx._h, 0x40))
+        hip._check(ctx.lib.milan_set_fusion(ctx._h, 0x80))
     ctx.close()
