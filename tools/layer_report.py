@@ -117,8 +117,11 @@ def main():
     print(f'encoder GEMMs: {tot_f/1e12:.2f} TFLOP in {tot_t/1e6:.1f} ms = '
           f'{tot_f/tot_t/1e3:.1f} TF/s')
     for k, (fl, du, c, m, nn, kk) in agg.items():
+        # round 6 (MILAN_FUSE_SPARSE_TAIL): the non-first blocks of the last stage run at the rows
+        # the level-4 pooling and their neighbourhoods need -- their TF/s here is DENSE-EQUIVALENT
+        note = '  (mask-aware rows: dense-equivalent TF/s)' if bneck and k.startswith('l4.x.') else ''
         print(f'{k:9s} x{c:2d} M={m:8d} N={nn:5d} K={kk:5d} {du/1e6:8.2f} ms '
-              f'{fl/du/1e3:6.1f} TF/s {100*du/tot_t:5.1f}%')
+              f'{fl/du/1e3:6.1f} TF/s {100*du/tot_t:5.1f}%{note}')
     dec = rows[len(layers):]
     print('decoder+lm GEMM launches', len(dec), 'time ms',
           sum(r[2] for r in dec) / 1e6)
