@@ -262,7 +262,21 @@ enum { MILAN_PRECISION_F32 = 0, MILAN_PRECISION_SPLIT_F16 = 1,
  *                     trunk launch is sized for the whole batch and reads the count
  *                     itself, workgroups beyond it exit -- nothing is read back and
  *                     the stream is never synchronised (rounds 5's form did both).
- * Default: all five (environment MILAN_CHAIN=<flags> overrides at context creation). */
+ *   MILAN_FUSE_BNECK  (round 6; needs MILAN_FUSE_CHAIN) layer1's 3x3 convolution -- and for the
+ *                     stage's first block its own 1x1 reduce conv -- run inside the block's
+ *                     chain launch, from an LDS copy of the input region (csrc/chain.hip,
+ *                     chain_kernel<.., CONV[, C1]>): the bottleneck's intermediate tensors
+ *                     (torchvision Bottleneck.forward: out of conv1 / conv2) never exist in
+ *                     memory.
+ *   MILAN_FUSE_SPARSE_TAIL  (round 6) the last stage's output is read by nothing but the
+ *                     level-4 pooling of src/milan/encoders.py:303-320, at the pixels under
+ *                     the shrunk mask: the last two bottlenecks run only at those pixels and
+ *                     the 3x3 neighbourhoods they depend on (row sets built on the device
+ *                     from the pooling's own pixel lists; dense when no masks are given).
+ * Default: all seven (environment MILAN_CHAIN=<flags> overrides at context creation).
+ * Not a flag but the same idea in the decoder: the rerank pass (decoders.py:495-512) scores
+ * one LM row per distinct beam PREFIX instead of one per beam (csrc/decoder.hip,
+ * lm_score_dedup; MILAN_LM_DEDUP=0 restores every row; same bits). */
 enum { MILAN_FUSE_CHAIN = 1,       /* planes <= 128 (layer1, layer2): HBM-bound, wins */
        MILAN_FUSE_CHAIN_WIDE = 2,  /* planes 256 (layer3): the role ping-pong of csrc/chain3.hip
                                       (round 5) */
